@@ -1,0 +1,184 @@
+// RMSNorm forward / backward for bf16 rows (HBM-bound; one pass over x).
+// Semantics follow nn.RMSNorm(D, eps) as used at reference modelling/llama.py:158,160,182:
+//   y = bf16( float(x) * rsqrt(mean(x^2) + eps) * float(w) )      -- single rounding.
+#include "common.h"
+
+// ---------------------------------------------------------------- forward
+// One wave per row, 4 rows per 256-thread block. Row values are kept in registers
+// (NCH chunks of 512 elements; lane owns 8 contiguous bf16 = one 16-B load per chunk).
+template <int NCH>
+__global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+                                                          bf16_t* __restrict__ y, float* __restrict__ rstd_out,
+                                                          int64_t rows, int dim, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const bf16_t* xr = x + row * dim;
+  u32x4_t v[NCH];
+  float ss = 0.f;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int col = c * 512 + lane * 8;
+    if (col < dim) {
+      v[c] = *reinterpret_cast<const u32x4_t*>(xr + col);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float a = bflo(v[c][e]), b = bfhi(v[c][e]);
+        ss += a * a + b * b;
+      }
+    }
+  }
+  ss = wave_sum(ss);
+  const float rstd = rsqrtf(ss / (float)dim + eps);
+  if (lane == 0 && rstd_out) rstd_out[row] = rstd;
+  bf16_t* yr = y + row * dim;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int col = c * 512 + lane * 8;
+    if (col < dim) {
+      u32x4_t wv = *reinterpret_cast<const u32x4_t*>(w + col);
+      u32x4_t o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float a = bflo(v[c][e]) * rstd * bflo(wv[e]);
+        float b = bfhi(v[c][e]) * rstd * bfhi(wv[e]);
+        o[e] = pack_bf2(a, b);
+      }
+      *reinterpret_cast<u32x4_t*>(yr + col) = o;
+    }
+  }
+}
+
+// ---------------------------------------------------------------- backward
+// Block per row-group: a 256-thread block walks `rows_per_block` rows; thread t owns columns
+// {c*2048 + t*8 .. +8}. dx is written per row; dw partial sums stay in registers and are
+// written once per block to dw_partial[blockIdx][dim] (fp32). A second kernel reduces them.
+//   xhat = x*rstd ; g = dy*w ; dx = rstd * (g - xhat * mean(g*xhat)) ; dw = sum_rows(dy*xhat)
+template <int NCH>
+__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
+                                                          const bf16_t* __restrict__ w, const float* __restrict__ rstd,
+                                                          bf16_t* __restrict__ dx, float* __restrict__ dw_partial,
+                                                          int64_t rows, int dim, int rows_per_block) {
+  __shared__ float red[16];
+  const int t = threadIdx.x;
+  float wv[NCH][8];
+  float dwacc[NCH][8];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int col = c * 2048 + t * 8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dwacc[c][e] = 0.f;
+    if (col < dim) {
+      u32x4_t u = *reinterpret_cast<const u32x4_t*>(w + col);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { wv[c][2 * e] = bflo(u[e]); wv[c][2 * e + 1] = bfhi(u[e]); }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) wv[c][e] = 0.f;
+    }
+  }
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  for (int64_t row = r0; row < r0 + rows_per_block && row < rows; ++row) {
+    const float rs = rstd[row];
+    float xh[NCH][8], g[NCH][8];
+    float dot = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int col = c * 2048 + t * 8;
+      if (col < dim) {
+        u32x4_t xv = *reinterpret_cast<const u32x4_t*>(x + row * dim + col);
+        u32x4_t dv = *reinterpret_cast<const u32x4_t*>(dy + row * dim + col);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float x0 = bflo(xv[e]) * rs, x1 = bfhi(xv[e]) * rs;
+          float d0 = bflo(dv[e]), d1 = bfhi(dv[e]);
+          xh[c][2 * e] = x0; xh[c][2 * e + 1] = x1;
+          dwacc[c][2 * e] += d0 * x0; dwacc[c][2 * e + 1] += d1 * x1;
+          g[c][2 * e] = d0 * wv[c][2 * e]; g[c][2 * e + 1] = d1 * wv[c][2 * e + 1];
+          dot += g[c][2 * e] * x0 + g[c][2 * e + 1] * x1;
+        }
+      }
+    }
+    dot = block_sum(dot, red);
+    const float m = dot / (float)dim;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int col = c * 2048 + t * 8;
+      if (col < dim) {
+        u32x4_t o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float a = rs * (g[c][2 * e] - xh[c][2 * e] * m);
+          float b = rs * (g[c][2 * e + 1] - xh[c][2 * e + 1] * m);
+          o[e] = pack_bf2(a, b);
+        }
+        *reinterpret_cast<u32x4_t*>(dx + row * dim + col) = o;
+      }
+    }
+  }
+  if (dw_partial) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int col = c * 2048 + t * 8;
+      if (col < dim) {
+        float* p = dw_partial + (int64_t)blockIdx.x * dim + col;
+        *reinterpret_cast<f32x4_t*>(p) = f32x4_t{dwacc[c][0], dwacc[c][1], dwacc[c][2], dwacc[c][3]};
+        *reinterpret_cast<f32x4_t*>(p + 4) = f32x4_t{dwacc[c][4], dwacc[c][5], dwacc[c][6], dwacc[c][7]};
+      }
+    }
+  }
+}
+
+// dw[col] = bf16( sum_p partial[p][col] ), optionally accumulating into an existing bf16 grad.
+__global__ void colsum_partials_kernel(const float* __restrict__ partial, bf16_t* __restrict__ out, int nparts, int dim,
+                                       int accumulate) {
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= dim) return;
+  float s = 0.f;
+  for (int p = 0; p < nparts; ++p) s += partial[(int64_t)p * dim + col];
+  if (accumulate) s += bf2f(out[col]);
+  out[col] = f2bf(s);
+}
+
+extern "C" int llx_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int64_t rows, int64_t dim, float eps,
+                               hipStream_t stream) {
+  LLX_REQUIRE(x && w && y, "llx_rmsnorm_fwd: null pointer");
+  LLX_REQUIRE(rows >= 0 && dim > 0 && dim % 8 == 0 && dim <= 8192, "llx_rmsnorm_fwd: dim=%lld must be a multiple of 8 and <= 8192",
+              (long long)dim);
+  if (rows == 0) return LLX_OK;
+  const dim3 grid((unsigned)cdiv64(rows, 4)), block(256);
+  const int nch = (int)cdiv64(dim, 512);
+#define L(N) hipLaunchKernelGGL(rmsnorm_fwd_kernel<N>, grid, block, 0, stream, (const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y, rstd, rows, (int)dim, eps)
+  if (nch <= 1) L(1); else if (nch <= 2) L(2); else if (nch <= 4) L(4); else if (nch <= 8) L(8); else L(16);
+#undef L
+  LLX_LAUNCH_CHECK("llx_rmsnorm_fwd");
+  return LLX_OK;
+}
+
+extern "C" int64_t llx_rmsnorm_bwd_workspace_bytes(int64_t rows, int64_t dim) {
+  const int64_t rpb = 16;
+  return cdiv64(rows, rpb) * dim * 4;
+}
+
+// dw may be null (frozen norm weight). workspace: llx_rmsnorm_bwd_workspace_bytes(rows, dim) bytes of fp32.
+extern "C" int llx_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rstd, void* dx, void* dw,
+                               int dw_accumulate, void* workspace, int64_t rows, int64_t dim, hipStream_t stream) {
+  LLX_REQUIRE(dy && x && w && rstd && dx, "llx_rmsnorm_bwd: null pointer");
+  LLX_REQUIRE(dim > 0 && dim % 8 == 0 && dim <= 8192, "llx_rmsnorm_bwd: dim=%lld must be a multiple of 8 and <= 8192", (long long)dim);
+  LLX_REQUIRE(!dw || workspace, "llx_rmsnorm_bwd: workspace required when dw is requested");
+  if (rows == 0) return LLX_OK;
+  const int rpb = 16;
+  const int nblk = (int)cdiv64(rows, rpb);
+  const int nch = (int)cdiv64(dim, 2048);
+  float* part = dw ? (float*)workspace : nullptr;
+#define L(N) hipLaunchKernelGGL(rmsnorm_bwd_kernel<N>, dim3(nblk), dim3(256), 0, stream, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)w, rstd, (bf16_t*)dx, part, rows, (int)dim, rpb)
+  if (nch <= 1) L(1); else if (nch <= 2) L(2); else L(4);
+#undef L
+  LLX_LAUNCH_CHECK("llx_rmsnorm_bwd");
+  if (dw) {
+    hipLaunchKernelGGL(colsum_partials_kernel, dim3((unsigned)cdiv64(dim, 256)), dim3(256), 0, stream, part, (bf16_t*)dw, nblk,
+                       (int)dim, dw_accumulate);
+    LLX_LAUNCH_CHECK("llx_rmsnorm_bwd(colsum)");
+  }
+  return LLX_OK;
+}

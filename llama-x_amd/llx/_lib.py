@@ -1,0 +1,73 @@
+"""ctypes binding of libllx_hip.so (the C-ABI declared in include/llx.h).
+
+The library is the only device arithmetic provider of this package: if it is missing or
+cannot be loaded the product path raises -- there is no CPU / eager fallback.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
+
+import torch  # noqa: F401  (must be imported first: it loads the HIP runtime this library binds to)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libllx_hip.so")
+
+_lib = None
+
+# name -> (restype, argtypes). Kept in step with include/llx.h (tests/test_abi.py checks both ways).
+_P, _I, _L, _F = c_void_p, c_int, c_int64, c_float
+SIGNATURES: dict[str, tuple] = {
+    "llx_version": (c_int, []),
+    "llx_last_error_string": (c_char_p, []),
+    "llx_device_info": (c_int, [c_int, c_char_p, c_int]),
+    "llx_rmsnorm_fwd": (c_int, [_P, _P, _P, _P, _L, _L, _F, _P]),
+    "llx_rmsnorm_bwd_workspace_bytes": (c_int64, [_L, _L]),
+    "llx_rmsnorm_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _I, _P, _L, _L, _P]),
+}
+
+
+class LlxError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library once; raise loudly if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise LlxError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C llama-x_amd/csrc`). There is no fallback path."
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = load().llx_last_error_string()
+        raise LlxError(f"{what} failed (code {rc}): {msg.decode() if msg else '?'}")
+
+
+def stream() -> c_void_p:
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t) -> c_void_p:
+    if t is None:
+        return c_void_p(0)
+    return c_void_p(t.data_ptr())
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise LlxError("llx ops run on the HIP device only (tensor on %s); there is no CPU path" % t.device)
