@@ -1,0 +1,233 @@
+// bf16 MFMA GEMM, "NT" form:  C[M,N] = A[M,K] . B[N,K]^T  (+ A2[M,K2] . B2[N,K2]^T)  with fused epilogues.
+//
+// This is the F.linear shape of the reference (modelling/llama.py:118-120,140,152,216; weight is [out,in]).
+// The backward data-gradient uses the same kernel on a transposed copy of the (frozen) weight, and the LoRA
+// adapter (modelling/lora.py:43) rides along as the K-extension (A2 = x.A^T, B2 = s.lora_b), so one tuned
+// kernel serves every dense contraction of the layer.
+//
+// Tile 256x256x64, 8 waves (2 along M x 4 along N), v_mfma_f32_16x16x32_bf16, fp32 accumulate.
+// HBM -> LDS by global_load_lds (16 B/lane) into two 64-KiB stages; the LDS image is lane-linear, so the
+// bank swizzle (16-B slot ^= (row>>1)&7 inside each 128-B row) is applied to the per-lane SOURCE address and
+// to the ds_read_b128 address.  The accumulators hold C^T fragments (mfma(B,A)), so each lane owns 4
+// consecutive output columns; the epilogue stages the bf16 tile through LDS and stores whole 512-B rows.
+#include "common.h"
+
+#define BM 256
+#define BN 256
+#define BK 64
+#define STAGE_BYTES (2 * 256 * BK * 2)          // A tile + B tile = 64 KiB
+#define A_TILE_BYTES (256 * BK * 2)             // 32 KiB
+#define EPI_ROW_BYTES 528                       // 512 B of bf16 + 16 B pad (bank spread for the ds_write_b64)
+#define GEMM_LDS_BYTES (256 * EPI_ROW_BYTES)    // 135168 >= 2 * STAGE_BYTES
+
+enum { EPI_NONE = 0, EPI_RESIDUAL = 1, EPI_BIAS = 2, EPI_BIAS_GELU = 3, EPI_COLSCALE = 4, EPI_ROWCOLSCALE = 5 };
+
+struct GemmArgs {
+  const bf16_t* A; const bf16_t* B; bf16_t* C;
+  const bf16_t* A2; const bf16_t* B2;
+  const bf16_t* E;   // residual [M,N] (ld = lde) | bias[N] | colscale[N]
+  const bf16_t* E2;  // rowscale[M] for EPI_ROWCOLSCALE
+  int64_t lda, ldb, ldc, lde, lda2, ldb2;
+  int M, N, K, K2;
+  int grid_m, grid_n;
+};
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_nt_bf16_kernel(const GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+
+  // ---- block -> tile: XCD-contiguous chunks (bijective remap), then 4-row groups for L2 panel reuse.
+  const int nwg = g.grid_m * g.grid_n;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
+    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+  }
+  const int GROUP_M = 4;
+  const int width = GROUP_M * g.grid_n;
+  const int group = bid / width;
+  const int gsz = min(g.grid_m - group * GROUP_M, GROUP_M);
+  const int pid_m = group * GROUP_M + ((bid % width) % gsz);
+  const int pid_n = (bid % width) / gsz;
+  const int m0 = pid_m * BM, n0 = pid_n * BN;
+
+  // ---- staging addresses. LDS chunk q = i*512 + tid  -> row i*64 + (tid>>3), slot tid&7;
+  // source chunk = slot ^ ((row>>1)&7) = (tid&7) ^ ((tid>>4)&7)   (independent of i).
+  const int srow = tid >> 3;
+  const int schunk = (tid & 7) ^ ((tid >> 4) & 7);
+  int arow[4], brow[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    arow[i] = min(m0 + i * 64 + srow, g.M - 1);  // clamp: edge rows re-read a valid row, never stored
+    brow[i] = min(n0 + i * 64 + srow, g.N - 1);
+  }
+  const int nk1 = g.K / BK;
+  const int nk = nk1 + g.K2 / BK;
+
+  auto stage = [&](int buf, int kt) {
+    char* sA = smem + buf * STAGE_BYTES;
+    char* sB = sA + A_TILE_BYTES;
+    const bf16_t* Ap; const bf16_t* Bp; int64_t la, lb; int k0;
+    if (kt < nk1) { Ap = g.A; Bp = g.B; la = g.lda; lb = g.ldb; k0 = kt * BK; }
+    else { Ap = g.A2; Bp = g.B2; la = g.lda2; lb = g.ldb2; k0 = (kt - nk1) * BK; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const bf16_t* src = Ap + (int64_t)arow[i] * la + k0 + schunk * 8;
+      __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(sA + (i * 512 + wave * 64) * 16), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const bf16_t* src = Bp + (int64_t)brow[i] * lb + k0 + schunk * 8;
+      __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(sB + (i * 512 + wave * 64) * 16), 16, 0, 0);
+    }
+  };
+
+  // ---- fragment read offsets (bytes inside a tile): row*128 + ((ks*4 + (lane>>4)) ^ ((lane>>1)&7))*16
+  const int frow = lane & 15;
+  const int fsw = (lane >> 1) & 7;
+  const int fq = lane >> 4;
+  const int a_base = (wm * 128 + frow) * 128;
+  const int b_base = (wn * 64 + frow) * 128;
+  const int slot0 = ((0 * 4 + fq) ^ fsw) * 16;
+  const int slot1 = ((1 * 4 + fq) ^ fsw) * 16;
+
+  f32x4_t acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  stage(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+    const char* sA = smem + cur * STAGE_BYTES;
+    const char* sB = sA + A_TILE_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int slot = ks ? slot1 : slot0;
+      bf16x8_t af[8], bfr[4];
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) bfr[ni] = *reinterpret_cast<const bf16x8_t*>(sB + b_base + ni * 16 * 128 + slot);
+#pragma unroll
+      for (int mi = 0; mi < 8; ++mi) af[mi] = *reinterpret_cast<const bf16x8_t*>(sA + a_base + mi * 16 * 128 + slot);
+#pragma unroll
+      for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ni], af[mi], acc[mi][ni], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  // ---- epilogue: acc (C^T fragments: lane owns n = fq*4..+4 for m = frow) -> bf16 -> LDS tile -> coalesced rows.
+#pragma unroll
+  for (int mi = 0; mi < 8; ++mi) {
+    const int m = wm * 128 + mi * 16 + frow;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      const int n = wn * 64 + ni * 16 + fq * 4;
+      u32x2_t pk;
+      pk[0] = pack_bf2(acc[mi][ni][0], acc[mi][ni][1]);
+      pk[1] = pack_bf2(acc[mi][ni][2], acc[mi][ni][3]);
+      *reinterpret_cast<u32x2_t*>(smem + m * EPI_ROW_BYTES + n * 2) = pk;
+    }
+  }
+  __syncthreads();
+#pragma unroll 4
+  for (int it = 0; it < 16; ++it) {
+    const int q = it * 512 + tid;
+    const int row = q >> 5, cc = q & 31;
+    const int gm = m0 + row, gn = n0 + cc * 8;
+    if (gm < g.M && gn < g.N) {
+      u32x4_t v = *reinterpret_cast<const u32x4_t*>(smem + row * EPI_ROW_BYTES + cc * 16);
+      if constexpr (EPI == EPI_RESIDUAL) {
+        // reference rounding: the linear's bf16 output is added to the bf16 residual (modelling/llama.py:172-173)
+        u32x4_t r = *reinterpret_cast<const u32x4_t*>(g.E + (int64_t)gm * g.lde + gn);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = pack_bf2(bflo(v[e]) + bflo(r[e]), bfhi(v[e]) + bfhi(r[e]));
+      } else if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) {
+        u32x4_t b = *reinterpret_cast<const u32x4_t*>(g.E + gn);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float lo = bflo(v[e]) + bflo(b[e]), hi = bfhi(v[e]) + bfhi(b[e]);
+          if constexpr (EPI == EPI_BIAS_GELU) {
+            lo = gelu_erf(bf2f(f2bf(lo)));
+            hi = gelu_erf(bf2f(f2bf(hi)));
+          }
+          v[e] = pack_bf2(lo, hi);
+        }
+      } else if constexpr (EPI == EPI_COLSCALE) {
+        // weight-only int8: (x @ W_i8^T) rounded to bf16, then * scale[n] (subclasses/int8.py:118)
+        u32x4_t s = *reinterpret_cast<const u32x4_t*>(g.E + gn);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = pack_bf2(bflo(v[e]) * bflo(s[e]), bfhi(v[e]) * bfhi(s[e]));
+      }
+      *reinterpret_cast<u32x4_t*>(g.C + (int64_t)gm * g.ldc + gn) = v;
+    }
+  }
+}
+
+static bool g_attr_set[8] = {false};
+
+template <int EPI>
+static int launch_gemm(const GemmArgs& a, hipStream_t stream) {
+  auto kern = gemm_nt_bf16_kernel<EPI>;
+  if (!g_attr_set[EPI]) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
+    if (e != hipSuccess) {
+      llx_set_error("llx_gemm_nt_bf16: cannot raise dynamic LDS limit: %s", hipGetErrorString(e));
+      return LLX_ERR_LAUNCH;
+    }
+    g_attr_set[EPI] = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(a.grid_m * a.grid_n), dim3(512), GEMM_LDS_BYTES, stream, a);
+  LLX_LAUNCH_CHECK("llx_gemm_nt_bf16");
+  return LLX_OK;
+}
+
+// C[M,N] = A[M,K].B[N,K]^T (+ A2[M,K2].B2[N,K2]^T), bf16 in/out, fp32 accumulate.
+// ld* are row strides in elements.  K and K2 must be multiples of 64, N a multiple of 8, all pointers and row
+// strides 16-byte aligned.  epilogue: 0 none | 1 +E[M,N] (ld=lde) | 2 +bias E[N] | 3 gelu(+bias) | 4 *colscale E[N].
+extern "C" int llx_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M,
+                                int64_t N, int64_t K, const void* A2, int64_t lda2, const void* B2, int64_t ldb2, int64_t K2,
+                                int epilogue, const void* E, int64_t lde, hipStream_t stream) {
+  LLX_REQUIRE(A && B && C, "llx_gemm_nt_bf16: null pointer");
+  LLX_REQUIRE(M > 0 && N > 0 && K > 0, "llx_gemm_nt_bf16: empty problem M=%lld N=%lld K=%lld", (long long)M, (long long)N, (long long)K);
+  LLX_REQUIRE(K % BK == 0 && K2 % BK == 0, "llx_gemm_nt_bf16: K=%lld and K2=%lld must be multiples of 64", (long long)K, (long long)K2);
+  LLX_REQUIRE(N % 8 == 0, "llx_gemm_nt_bf16: N=%lld must be a multiple of 8", (long long)N);
+  LLX_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && ldc % 8 == 0, "llx_gemm_nt_bf16: row strides must be multiples of 8 elements");
+  LLX_REQUIRE(((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) % 16 == 0, "llx_gemm_nt_bf16: pointers must be 16-byte aligned");
+  LLX_REQUIRE(K2 == 0 || (A2 && B2 && lda2 % 8 == 0 && ldb2 % 8 == 0 && ((uintptr_t)A2 | (uintptr_t)B2) % 16 == 0),
+              "llx_gemm_nt_bf16: bad K-extension operands");
+  LLX_REQUIRE(epilogue == EPI_NONE || (E && (uintptr_t)E % 16 == 0), "llx_gemm_nt_bf16: epilogue operand missing/unaligned");
+  LLX_REQUIRE(epilogue != EPI_RESIDUAL || lde % 8 == 0, "llx_gemm_nt_bf16: residual stride must be a multiple of 8");
+  LLX_REQUIRE(M < (1 << 30) && N < (1 << 30) && K < (1 << 30), "llx_gemm_nt_bf16: dimension too large");
+  GemmArgs a;
+  a.A = (const bf16_t*)A; a.B = (const bf16_t*)B; a.C = (bf16_t*)C;
+  a.A2 = (const bf16_t*)A2; a.B2 = (const bf16_t*)B2; a.E = (const bf16_t*)E; a.E2 = nullptr;
+  a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.lde = lde; a.lda2 = lda2; a.ldb2 = ldb2;
+  a.M = (int)M; a.N = (int)N; a.K = (int)K; a.K2 = (int)K2;
+  a.grid_m = (int)cdiv64(M, BM); a.grid_n = (int)cdiv64(N, BN);
+  switch (epilogue) {
+    case EPI_NONE: return launch_gemm<EPI_NONE>(a, stream);
+    case EPI_RESIDUAL: return launch_gemm<EPI_RESIDUAL>(a, stream);
+    case EPI_BIAS: return launch_gemm<EPI_BIAS>(a, stream);
+    case EPI_BIAS_GELU: return launch_gemm<EPI_BIAS_GELU>(a, stream);
+    case EPI_COLSCALE: return launch_gemm<EPI_COLSCALE>(a, stream);
+    default: llx_set_error("llx_gemm_nt_bf16: unknown epilogue %d", epilogue); return LLX_ERR_UNSUPPORTED;
+  }
+}
