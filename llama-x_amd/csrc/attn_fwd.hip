@@ -1,0 +1,277 @@
+// Flash-style attention forward for head_dim 128, GQA by head indexing, masks from per-token metadata.
+//
+// Replaces F.scaled_dot_product_attention(..., enable_gqa=True) and flex_attention(block_mask=...) of the
+// reference (modelling/llama.py:129-137).  Mask rule (bit-exact with the reference's mask functions):
+//     allow(q, k) = (k <= q  ||  k < prefix_len[b])  &&  (doc_ids == null || doc_ids[b,q] == doc_ids[b,k])
+//   * causal:       prefix_len = null, doc_ids = null        (is_causal=True, modelling/llama.py:135)
+//   * document:     doc_ids given                            (mask_mod, train_metamathqa.py:67-68)
+//   * prefix-LM:    prefix_len given                         (README.md:16 plan)
+// Layout: q [B,S,H,128], k/v [B,S,KVH,128] with arbitrary batch/sequence strides (so views of a fused QKV
+// projection work), o [B,S,H,128] contiguous per row, lse [B,H,S] fp32 in log2 units (for the backward).
+//
+// One workgroup = 4 waves = 128 query rows of one (batch, head); each wave owns 32 rows.  Per 64-key tile:
+//   S^T = K.Q^T   (keys on accumulator rows, the query row on the lane -> softmax statistics are lane-local)
+//   O^T += V^T.P^T (P^T taken straight from the S^T accumulator registers as the MFMA B operand; V^T fragments
+//                   come from the row-major LDS tile through ds_read_b64_tr_b16)
+// K/V tiles are double-buffered in LDS by global_load_lds with the bank swizzle applied on the source address.
+#include "common.h"
+
+#define HD 128
+#define BQ 128
+#define BKV 64
+#define KV_TILE_BYTES (BKV * HD * 2)        // 16 KiB
+#define ATT_STAGE_BYTES (2 * KV_TILE_BYTES)  // K + V
+#define ATT_LDS_BYTES (2 * ATT_STAGE_BYTES)  // 64 KiB
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
+typedef __attribute__((address_space(3))) s16x4_t lds_s16x4;
+
+struct AttnFwdArgs {
+  const bf16_t* q; const bf16_t* k; const bf16_t* v; bf16_t* o; float* lse;
+  int64_t q_sb, q_ss, k_sb, k_ss, v_sb, v_ss, o_sb, o_ss;  // element strides (batch, sequence)
+  const int* doc_ids;     // [B,S] or null
+  const int* prefix_len;  // [B] or null
+  const uint8_t* flags;   // [B, nqb, nkt] tile classes (0 skip, 1 partial, 2 full) or null => causal arithmetic
+  int B, S, H, KVH;
+  float scale_log2;       // softmax scale * log2(e)
+};
+
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnFwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nqb = (a.S + BQ - 1) / BQ, nkt = (a.S + BKV - 1) / BKV;
+  const int qb = nqb - 1 - blockIdx.x;  // heaviest (longest causal rows) first
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int kvh = h / (a.H / a.KVH);
+  const int r = lane & 31, hh = lane >> 5;
+  const int qi = qb * BQ + wave * 32 + r;  // this lane's query row
+  const int qrow = min(qi, a.S - 1);
+
+  // ---- Q fragments (B operand of S^T = K.Q^T): Q[q=r][d = 16ks + 8hh + j]
+  bf16x8_t qf[8];
+  {
+    const bf16_t* qp = a.q + (int64_t)b * a.q_sb + (int64_t)qrow * a.q_ss + h * HD + 8 * hh;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) qf[ks] = *reinterpret_cast<const bf16x8_t*>(qp + 16 * ks);
+  }
+
+  // ---- tile schedule
+  const uint8_t* fl = a.flags ? a.flags + ((int64_t)b * nqb + qb) * nkt : nullptr;
+  const int kt_end = fl ? nkt : min(nkt, (qb * BQ + BQ + BKV - 1) / BKV);
+  auto tile_class = [&](int t) -> int {
+    if (fl) return fl[t];
+    return (t * BKV + BKV - 1 <= qb * BQ) ? 2 : 1;  // all keys <= first query row of the block => no masking
+  };
+  auto next_tile = [&](int t) {
+    while (t < kt_end && tile_class(t) == 0) ++t;
+    return t;
+  };
+
+  // ---- staging: 16 KiB tile = 16 wave-instructions of 1 KiB (4 rows x 256 B); lane -> row l>>4, slot l&15
+  const int srow_in = lane >> 4, sslot = lane & 15;
+  const bf16_t* kbase = a.k + (int64_t)b * a.k_sb + kvh * HD;
+  const bf16_t* vbase = a.v + (int64_t)b * a.v_sb + kvh * HD;
+  auto stage = [&](int buf, int t) {
+    char* sK = smem + buf * ATT_STAGE_BYTES;
+    char* sV = sK + KV_TILE_BYTES;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = i * 16 + wave * 4 + srow_in;
+      const int key = min(t * BKV + row, a.S - 1);
+      const int kc = sslot ^ (row & 15);          // K image: slot = chunk ^ (row & 15)
+      const int vc = sslot ^ ((row & 3) << 2);    // V image: slot = chunk ^ ((row & 3) << 2)
+      __builtin_amdgcn_global_load_lds((gbl_void*)(kbase + (int64_t)key * a.k_ss + kc * 8),
+                                       (lds_void*)(sK + (i * 16 + wave * 4) * 256), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_void*)(vbase + (int64_t)key * a.v_ss + vc * 8),
+                                       (lds_void*)(sV + (i * 16 + wave * 4) * 256), 16, 0, 0);
+    }
+  };
+
+  f32x16_t o[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o[i][e] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  const int my_doc = a.doc_ids ? a.doc_ids[(int64_t)b * a.S + qrow] : 0;
+  const int my_prefix = a.prefix_len ? a.prefix_len[b] : 0;
+
+  // tr-read lane constants: group-local i = lane&15 -> q4 = i>>2 (row in block), p = i&3
+  const int tq = (lane & 15) >> 2, tp = lane & 3;
+  const int tsub = (lane >> 4) & 1;
+
+  int t = next_tile(0);
+  if (t < kt_end) stage(0, t);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int cur = 0;
+  while (t < kt_end) {
+    const int tn = next_tile(t + 1);
+    if (tn < kt_end) stage(cur ^ 1, tn);
+    const char* sK = smem + cur * ATT_STAGE_BYTES;
+    const char* sV = sK + KV_TILE_BYTES;
+
+    // ---- S^T = K.Q^T : 2 key blocks x 8 k-steps
+    f32x16_t st[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) st[kb][e] = 0.f;
+      const int row = kb * 32 + r;
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(sK + row * 256 + (((2 * ks + hh) ^ (row & 15)) << 4));
+        st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], st[kb], 0, 0, 0);
+      }
+    }
+
+    // ---- scale, mask, online softmax (row statistics are per lane; the partner half-wave holds the other keys)
+    const int cls = tile_class(t);
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        float s = st[kb][e] * a.scale_log2;
+        if (cls != 2) {
+          const int kk = t * BKV + kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+          bool ok = (kk < a.S) && (kk <= qi || kk < my_prefix);
+          if (a.doc_ids) ok = ok && (a.doc_ids[(int64_t)b * a.S + min(kk, a.S - 1)] == my_doc);
+          s = ok ? s : -INFINITY;
+        }
+        st[kb][e] = s;
+        mx = fmaxf(mx, s);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
+    const float alpha = exp2f(m_run - m_safe);  // m_run = -inf -> 0
+    float rs = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        float p = exp2f(st[kb][e] - m_safe);
+        st[kb][e] = p;
+        rs += p;
+      }
+    rs += __shfl_xor(rs, 32, 64);
+    l_run = l_run * alpha + rs;
+    m_run = m_new;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) o[i][e] *= alpha;
+
+    // ---- O^T += V^T.P^T : P^T k-step (kb, s) = accumulator regs 8s..8s+7; element j <-> key 32kb+16s+8(j>>2)+4hh+(j&3)
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        bf16x8_t pb;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pb[j] = (__bf16)st[kb][8 * s + j];
+        const int key0 = kb * 32 + s * 16 + 4 * hh;
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+          const int chunk = 4 * db + 2 * tsub + (tp >> 1);
+          const int row_lo = key0 + tq, row_hi = key0 + 8 + tq;
+          // (row & 3) == tq for both rows (key0 and key0+8 are multiples of 4)
+          const int off = (((chunk ^ (tq << 2)) << 4) | ((tp & 1) << 3));
+          s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(sV + row_lo * 256 + off));
+          s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(sV + row_hi * 256 + off));
+          typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+          s16x8_t vv = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, vv), pb, o[db], 0, 0, 0);
+        }
+      }
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    cur ^= 1;
+    t = tn;
+  }
+
+  // ---- finalize: O = O^T / l ; lse = m + log2(l)
+  if (qi < a.S) {
+    const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
+    bf16_t* op = a.o + (int64_t)b * a.o_sb + (int64_t)qi * a.o_ss + h * HD;
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        u32x2_t pk;
+        pk[0] = pack_bf2(o[db][4 * g4 + 0] * inv, o[db][4 * g4 + 1] * inv);
+        pk[1] = pack_bf2(o[db][4 * g4 + 2] * inv, o[db][4 * g4 + 3] * inv);
+        *reinterpret_cast<u32x2_t*>(op + 32 * db + 8 * g4 + 4 * hh) = pk;
+      }
+    if (hh == 0 && a.lse) a.lse[((int64_t)b * a.H + h) * a.S + qi] = (l_run > 0.f) ? m_run + log2f(l_run) : -INFINITY;
+  }
+}
+
+// Tile classes for non-causal-only masks: flags[b][qb][kt] = 0 (no pair allowed) | 1 (some) | 2 (all, no masking).
+__global__ void attn_tile_flags_kernel(const int* __restrict__ doc_ids, const int* __restrict__ prefix_len, uint8_t* flags, int S,
+                                       int nqb, int nkt) {
+  __shared__ int s_any, s_all;
+  const int kt = blockIdx.x, qb = blockIdx.y, b = blockIdx.z;
+  if (threadIdx.x == 0) { s_any = 0; s_all = 1; }
+  __syncthreads();
+  const int P = prefix_len ? prefix_len[b] : 0;
+  int any = 0, all = 1;
+  for (int idx = threadIdx.x; idx < BQ * BKV; idx += blockDim.x) {
+    const int qi = qb * BQ + idx / BKV, kk = kt * BKV + idx % BKV;
+    if (qi >= S) continue;  // rows past the end do not constrain the class
+    bool ok = (kk < S) && (kk <= qi || kk < P);
+    if (ok && doc_ids) ok = doc_ids[(int64_t)b * S + qi] == doc_ids[(int64_t)b * S + kk];
+    any |= ok; all &= ok;
+  }
+  if (any) atomicOr(&s_any, 1);
+  if (!all) atomicAnd(&s_all, 0);
+  __syncthreads();
+  if (threadIdx.x == 0) flags[((int64_t)b * nqb + qb) * nkt + kt] = s_any ? (s_all ? 2 : 1) : 0;
+}
+
+static bool g_attn_attr = false;
+
+extern "C" int64_t llx_attn_flags_bytes(int64_t B, int64_t S) { return B * cdiv64(S, BQ) * cdiv64(S, BKV); }
+
+// flags: llx_attn_flags_bytes(B,S) bytes (device), filled here. Needed only when doc_ids or prefix_len is used.
+extern "C" int llx_attn_tile_flags(const int* doc_ids, const int* prefix_len, void* flags, int64_t B, int64_t S, hipStream_t stream) {
+  LLX_REQUIRE(flags && B > 0 && S > 0, "llx_attn_tile_flags: bad arguments");
+  const int nqb = (int)cdiv64(S, BQ), nkt = (int)cdiv64(S, BKV);
+  hipLaunchKernelGGL(attn_tile_flags_kernel, dim3(nkt, nqb, (unsigned)B), dim3(256), 0, stream, doc_ids, prefix_len, (uint8_t*)flags,
+                     (int)S, nqb, nkt);
+  LLX_LAUNCH_CHECK("llx_attn_tile_flags");
+  return LLX_OK;
+}
+
+// strides are in elements: *_sb per batch, *_ss per sequence position; head h starts at element h*128 of a row.
+extern "C" int llx_attn_fwd(const void* q, int64_t q_sb, int64_t q_ss, const void* k, int64_t k_sb, int64_t k_ss, const void* v,
+                            int64_t v_sb, int64_t v_ss, void* o, int64_t o_sb, int64_t o_ss, float* lse, const int* doc_ids,
+                            const int* prefix_len, const void* flags, int64_t B, int64_t S, int64_t H, int64_t KVH, int64_t head_dim,
+                            float scale, hipStream_t stream) {
+  LLX_REQUIRE(q && k && v && o, "llx_attn_fwd: null pointer");
+  LLX_REQUIRE(head_dim == HD, "llx_attn_fwd: head_dim=%lld unsupported (only 128)", (long long)head_dim);
+  LLX_REQUIRE(B > 0 && S > 0 && H > 0 && KVH > 0 && H % KVH == 0, "llx_attn_fwd: bad B/S/H/KVH");
+  LLX_REQUIRE((q_ss % 8 | k_ss % 8 | v_ss % 8 | o_ss % 4 | q_sb % 8 | k_sb % 8 | v_sb % 8 | o_sb % 4) == 0, "llx_attn_fwd: strides must keep 16-byte alignment");
+  LLX_REQUIRE(((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) % 16 == 0 && (uintptr_t)o % 8 == 0, "llx_attn_fwd: unaligned pointer");
+  LLX_REQUIRE(!(doc_ids || prefix_len) || flags, "llx_attn_fwd: tile flags required with doc_ids/prefix_len");
+  LLX_REQUIRE(S < (1 << 24), "llx_attn_fwd: S too large");
+  if (!g_attn_attr) {
+    hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS_BYTES);
+    if (e != hipSuccess) { llx_set_error("llx_attn_fwd: %s", hipGetErrorString(e)); return LLX_ERR_LAUNCH; }
+    g_attn_attr = true;
+  }
+  AttnFwdArgs a;
+  a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.o = (bf16_t*)o; a.lse = lse;
+  a.q_sb = q_sb; a.q_ss = q_ss; a.k_sb = k_sb; a.k_ss = k_ss; a.v_sb = v_sb; a.v_ss = v_ss; a.o_sb = o_sb; a.o_ss = o_ss;
+  a.doc_ids = doc_ids; a.prefix_len = prefix_len; a.flags = (doc_ids || prefix_len) ? (const uint8_t*)flags : nullptr;
+  a.B = (int)B; a.S = (int)S; a.H = (int)H; a.KVH = (int)KVH;
+  a.scale_log2 = scale * 1.4426950408889634f;
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)cdiv64(S, BQ), (unsigned)H, (unsigned)B), dim3(256), ATT_LDS_BYTES, stream, a);
+  LLX_LAUNCH_CHECK("llx_attn_fwd");
+  return LLX_OK;
+}
