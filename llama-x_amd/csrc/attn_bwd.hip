@@ -1,0 +1,425 @@
+// Flash-style attention backward (head_dim 128, GQA, same mask rule as attn_fwd.hip).
+//
+// Gradients of softmax(QK^T*scale + mask)V as autograd produces them for the reference's SDPA / FlexAttention
+// call (modelling/llama.py:129-137).  P is recomputed from Q, K and the forward's log2-sum-exp.  Deterministic:
+// no atomics.  Three launches:
+//   1. attn_delta_kernel : delta[b,h,q] = sum_d dO.O
+//   2. attn_bwd_dq_kernel: one workgroup = 128 query rows of one head, sweeps key tiles      -> dQ
+//   3. attn_bwd_dkv_kernel: one workgroup = 128 keys of one KV head, sweeps the G query heads
+//                           of its group x 64-row query tiles                                -> dK, dV
+// MFMA orientation keeps the softmax row index where the row constants (lse, delta) are cheap:
+//   dq kernel : S^T = K.Q^T, dP^T = V.dO^T (query on the lane), dQ^T += K^T.dS^T with dS^T taken from the accumulator
+//               registers as the B operand and K^T read from the SAME LDS image by ds_read_b64_tr_b16.
+//   dkv kernel: S = Q.K^T, dP = dO.V^T (key on the lane, K/V fragments live in registers), dV^T += dO^T.P,
+//               dK^T += Q^T.dS with P/dS from the accumulator registers and Q^T/dO^T by transposed LDS reads.
+// LDS images read both by rows and transposed use the dual-use swizzle  slot = chunk ^ (((row&3)<<2) | ((row>>2)&3)).
+#include "common.h"
+
+#define HD 128
+#define BQ 128
+#define BKV 64
+#define TILE_BYTES (64 * HD * 2)  // a 64-row x 128-col bf16 tile = 16 KiB
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
+typedef __attribute__((address_space(3))) s16x4_t lds_s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+
+__device__ __forceinline__ int dual_swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+
+// A-operand fragment (32 rows x 16 k) read TRANSPOSED from a dual-use [rows][128] bf16 LDS image:
+// returns X^T[col = 32*db + (lane&31)][row = row0 + 8*(j>>2) + 4*hh + (j&3)], j = 0..7  (row0 multiple of 16).
+__device__ __forceinline__ bf16x8_t tr_frag(const char* img, int row0, int db, int lane) {
+  const int hh = lane >> 5, tq = (lane & 15) >> 2, tp = lane & 3, tsub = (lane >> 4) & 1;
+  const int chunk = 4 * db + 2 * tsub + (tp >> 1);
+  const int rlo = row0 + 4 * hh + tq, rhi = rlo + 8;
+  s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + rlo * 256 + ((chunk ^ dual_swz(rlo)) << 4) + ((tp & 1) << 3)));
+  s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + rhi * 256 + ((chunk ^ dual_swz(rhi)) << 4) + ((tp & 1) << 3)));
+  s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8_t, v);
+}
+
+// Row fragment (A operand rows = image rows, k = 16*ks + 8*hh + j) from a dual-use image.
+__device__ __forceinline__ bf16x8_t row_frag(const char* img, int row, int ks, int hh) {
+  return *reinterpret_cast<const bf16x8_t*>(img + row * 256 + (((2 * ks + hh) ^ dual_swz(row)) << 4));
+}
+
+struct AttnBwdArgs {
+  const bf16_t* q; const bf16_t* k; const bf16_t* v; const bf16_t* o; const bf16_t* d_o;
+  const float* lse; float* delta;
+  bf16_t* dq; bf16_t* dk; bf16_t* dv;
+  int64_t q_sb, q_ss, k_sb, k_ss, v_sb, v_ss, o_sb, o_ss, do_sb, do_ss;
+  int64_t dq_sb, dq_ss, dk_sb, dk_ss, dv_sb, dv_ss;
+  const int* doc_ids; const int* prefix_len; const uint8_t* flags;
+  int B, S, H, KVH;
+  float scale, scale_log2;
+};
+
+// ------------------------------------------------------------------------------------------ delta
+__global__ void attn_delta_kernel(const AttnBwdArgs a) {
+  // 16 lanes per (q, h) row of 128 elements; 16 rows per 256-thread block
+  const int64_t row = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+  const int sub = threadIdx.x & 15;
+  const int64_t total = (int64_t)a.B * a.S * a.H;
+  float acc = 0.f;
+  if (row < total) {
+    const int h = (int)(row % a.H);
+    const int64_t bs = row / a.H;
+    const int s = (int)(bs % a.S), b = (int)(bs / a.S);
+    u32x4_t x = *reinterpret_cast<const u32x4_t*>(a.o + b * a.o_sb + s * a.o_ss + h * HD + sub * 8);
+    u32x4_t y = *reinterpret_cast<const u32x4_t*>(a.d_o + b * a.do_sb + s * a.do_ss + h * HD + sub * 8);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc += bflo(x[e]) * bflo(y[e]) + bfhi(x[e]) * bfhi(y[e]);
+  }
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if (row < total && sub == 0) {
+    const int h = (int)(row % a.H);
+    const int64_t bs = row / a.H;
+    const int s = (int)(bs % a.S), b = (int)(bs / a.S);
+    a.delta[((int64_t)b * a.H + h) * a.S + s] = acc;
+  }
+}
+
+// ------------------------------------------------------------------------------------------ dQ
+#define DQ_STAGE_BYTES (2 * TILE_BYTES)
+#define DQ_LDS_BYTES (2 * DQ_STAGE_BYTES)
+
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nqb = (a.S + BQ - 1) / BQ, nkt = (a.S + BKV - 1) / BKV;
+  const int qb = nqb - 1 - blockIdx.x;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int kvh = h / (a.H / a.KVH);
+  const int r = lane & 31, hh = lane >> 5;
+  const int qi = qb * BQ + wave * 32 + r;
+  const int qrow = min(qi, a.S - 1);
+
+  bf16x8_t qf[8], dof[8];
+  {
+    const bf16_t* qp = a.q + (int64_t)b * a.q_sb + (int64_t)qrow * a.q_ss + h * HD + 8 * hh;
+    const bf16_t* dp = a.d_o + (int64_t)b * a.do_sb + (int64_t)qrow * a.do_ss + h * HD + 8 * hh;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      qf[ks] = *reinterpret_cast<const bf16x8_t*>(qp + 16 * ks);
+      dof[ks] = *reinterpret_cast<const bf16x8_t*>(dp + 16 * ks);
+    }
+  }
+  const float my_lse = a.lse[((int64_t)b * a.H + h) * a.S + qrow];
+  const float my_delta = a.delta[((int64_t)b * a.H + h) * a.S + qrow];
+  const float lse_safe = (my_lse == -INFINITY) ? 0.f : my_lse;
+
+  const uint8_t* fl = a.flags ? a.flags + ((int64_t)b * nqb + qb) * nkt : nullptr;
+  const int kt_end = fl ? nkt : min(nkt, (qb * BQ + BQ + BKV - 1) / BKV);
+  auto tile_class = [&](int t) -> int {
+    if (fl) return fl[t];
+    return (t * BKV + BKV - 1 <= qb * BQ) ? 2 : 1;
+  };
+  auto next_tile = [&](int t) {
+    while (t < kt_end && tile_class(t) == 0) ++t;
+    return t;
+  };
+
+  const int srow_in = lane >> 4, sslot = lane & 15;
+  const bf16_t* kbase = a.k + (int64_t)b * a.k_sb + kvh * HD;
+  const bf16_t* vbase = a.v + (int64_t)b * a.v_sb + kvh * HD;
+  auto stage = [&](int buf, int t) {
+    char* sK = smem + buf * DQ_STAGE_BYTES;
+    char* sV = sK + TILE_BYTES;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = i * 16 + wave * 4 + srow_in;
+      const int key = min(t * BKV + row, a.S - 1);
+      const int kc = sslot ^ dual_swz(row);  // K: dual-use image (row reads for S^T, transposed reads for dQ^T)
+      const int vc = sslot ^ (row & 15);     // V: row reads only
+      __builtin_amdgcn_global_load_lds((gbl_void*)(kbase + (int64_t)key * a.k_ss + kc * 8), (lds_void*)(sK + (i * 16 + wave * 4) * 256), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_void*)(vbase + (int64_t)key * a.v_ss + vc * 8), (lds_void*)(sV + (i * 16 + wave * 4) * 256), 16, 0, 0);
+    }
+  };
+
+  f32x16_t dq[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) dq[i][e] = 0.f;
+  const int my_doc = a.doc_ids ? a.doc_ids[(int64_t)b * a.S + qrow] : 0;
+  const int my_prefix = a.prefix_len ? a.prefix_len[b] : 0;
+
+  int t = next_tile(0);
+  if (t < kt_end) stage(0, t);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int cur = 0;
+  while (t < kt_end) {
+    const int tn = next_tile(t + 1);
+    if (tn < kt_end) stage(cur ^ 1, tn);
+    const char* sK = smem + cur * DQ_STAGE_BYTES;
+    const char* sV = sK + TILE_BYTES;
+    const int cls = tile_class(t);
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      f32x16_t st, dp;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { st[e] = 0.f; dp[e] = 0.f; }
+      const int row = kb * 32 + r;
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        bf16x8_t kf = row_frag(sK, row, ks, hh);
+        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], st, 0, 0, 0);
+        bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(sV + row * 256 + (((2 * ks + hh) ^ (row & 15)) << 4));
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[ks], dp, 0, 0, 0);
+      }
+      // dS^T = P^T * (dP^T - delta)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        float p = exp2f(st[e] * a.scale_log2 - lse_safe);
+        if (cls != 2) {
+          const int kk = t * BKV + kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+          bool ok = (kk < a.S) && (kk <= qi || kk < my_prefix);
+          if (a.doc_ids) ok = ok && (a.doc_ids[(int64_t)b * a.S + min(kk, a.S - 1)] == my_doc);
+          p = ok ? p : 0.f;
+        }
+        st[e] = p * (dp[e] - my_delta);
+      }
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        bf16x8_t dsb;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dsb[j] = (__bf16)st[8 * s + j];
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+          bf16x8_t kt_f = tr_frag(sK, kb * 32 + s * 16, db, lane);
+          dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kt_f, dsb, dq[db], 0, 0, 0);
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    cur ^= 1;
+    t = tn;
+  }
+
+  if (qi < a.S) {
+    bf16_t* op = a.dq + (int64_t)b * a.dq_sb + (int64_t)qi * a.dq_ss + h * HD;
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        u32x2_t pk;
+        pk[0] = pack_bf2(dq[db][4 * g4 + 0] * a.scale, dq[db][4 * g4 + 1] * a.scale);
+        pk[1] = pack_bf2(dq[db][4 * g4 + 2] * a.scale, dq[db][4 * g4 + 3] * a.scale);
+        *reinterpret_cast<u32x2_t*>(op + 32 * db + 8 * g4 + 4 * hh) = pk;
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------ dK, dV
+#define DKV_QT 64
+#define DKV_STAGE_BYTES (2 * TILE_BYTES + 512)  // Q tile + dO tile + lse[64] + delta[64]
+#define DKV_LDS_BYTES (2 * DKV_STAGE_BYTES)
+
+__global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const AttnBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nqb = (a.S + BQ - 1) / BQ, nkt = (a.S + BKV - 1) / BKV;
+  const int nqt = (a.S + DKV_QT - 1) / DKV_QT;
+  const int kblk = blockIdx.x;  // 128-key block; low blocks see the most query tiles under a causal mask
+  const int kvh = blockIdx.y, b = blockIdx.z;
+  const int G = a.H / a.KVH;
+  const int r = lane & 31, hh = lane >> 5;
+  const int key = kblk * 128 + wave * 32 + r;  // this lane's key
+  const int krow = min(key, a.S - 1);
+  const int my_kt = 2 * kblk + (wave >> 1);    // 64-key tile index of this wave (for the tile classes)
+
+  // K / V fragments as B operands: X[key = r][d = 16ks + 8hh + j]
+  bf16x8_t kf[8], vf[8];
+  {
+    const bf16_t* kp = a.k + (int64_t)b * a.k_sb + (int64_t)krow * a.k_ss + kvh * HD + 8 * hh;
+    const bf16_t* vp = a.v + (int64_t)b * a.v_sb + (int64_t)krow * a.v_ss + kvh * HD + 8 * hh;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      kf[ks] = *reinterpret_cast<const bf16x8_t*>(kp + 16 * ks);
+      vf[ks] = *reinterpret_cast<const bf16x8_t*>(vp + 16 * ks);
+    }
+  }
+  const int key_doc = a.doc_ids ? a.doc_ids[(int64_t)b * a.S + krow] : 0;
+  const int my_prefix = a.prefix_len ? a.prefix_len[b] : 0;
+
+  // ---- schedule: iteration it = g * nqt + qt over (head of the group, 64-row query tile)
+  const int qt_first = a.flags ? 0 : (kblk * 128) / DKV_QT;  // causal: rows before the block's first key see none of it
+  auto block_class = [&](int qt, int kt) -> int {  // class of (query tile qt, key tile kt)
+    if (a.flags) return a.flags[((int64_t)b * nqb + (qt >> 1)) * nkt + min(kt, nkt - 1)];
+    const int q_lo = qt * DKV_QT, q_hi = q_lo + DKV_QT - 1, k_lo = kt * BKV, k_hi = k_lo + BKV - 1;
+    if (k_lo > q_hi) return 0;
+    return (k_hi <= q_lo) ? 2 : 1;
+  };
+  auto tile_live = [&](int qt) -> bool {
+    return block_class(qt, 2 * kblk) != 0 || (2 * kblk + 1 < nkt && block_class(qt, 2 * kblk + 1) != 0);
+  };
+  const int n_it = G * nqt;
+  auto next_it = [&](int it) {
+    while (it < n_it) {
+      const int qt = it % nqt;
+      if (qt >= qt_first && tile_live(qt)) break;
+      ++it;
+    }
+    return it;
+  };
+
+  const int srow_in = lane >> 4, sslot = lane & 15;
+  auto stage = [&](int buf, int it) {
+    const int g = it / nqt, qt = it % nqt;
+    const int h = kvh * G + g;
+    char* sQ = smem + buf * DKV_STAGE_BYTES;
+    char* sD = sQ + TILE_BYTES;
+    char* sL = sD + TILE_BYTES;
+    const bf16_t* qbase = a.q + (int64_t)b * a.q_sb + h * HD;
+    const bf16_t* dbase = a.d_o + (int64_t)b * a.do_sb + h * HD;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = i * 16 + wave * 4 + srow_in;
+      const int qr = min(qt * DKV_QT + row, a.S - 1);
+      const int c = sslot ^ dual_swz(row);
+      __builtin_amdgcn_global_load_lds((gbl_void*)(qbase + (int64_t)qr * a.q_ss + c * 8), (lds_void*)(sQ + (i * 16 + wave * 4) * 256), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_void*)(dbase + (int64_t)qr * a.do_ss + c * 8), (lds_void*)(sD + (i * 16 + wave * 4) * 256), 16, 0, 0);
+    }
+    if (wave < 2) {  // wave 0: lse[64], wave 1: delta[64]
+      const float* src = (wave == 0 ? a.lse : a.delta) + ((int64_t)b * a.H + h) * a.S + min(qt * DKV_QT + lane, a.S - 1);
+      __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(sL + wave * 256), 4, 0, 0);
+    }
+  };
+
+  f32x16_t dk[4], dv[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { dk[i][e] = 0.f; dv[i][e] = 0.f; }
+
+  int it = next_it(0);
+  if (it < n_it) stage(0, it);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int cur = 0;
+  while (it < n_it) {
+    const int itn = next_it(it + 1);
+    if (itn < n_it) stage(cur ^ 1, itn);
+    const int qt = it % nqt;
+    const char* sQ = smem + cur * DKV_STAGE_BYTES;
+    const char* sD = sQ + TILE_BYTES;
+    const float* sL = reinterpret_cast<const float*>(sD + TILE_BYTES);
+    int cls = block_class(qt, my_kt);
+    if (my_kt >= nkt) cls = 0;
+    if (cls == 2 && (qt * DKV_QT + DKV_QT > a.S)) cls = 1;  // rows past the end must be masked out of dK/dV
+    if (cls != 0) {
+#pragma unroll
+      for (int qb32 = 0; qb32 < 2; ++qb32) {
+        f32x16_t st, dp;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { st[e] = 0.f; dp[e] = 0.f; }
+        const int row = qb32 * 32 + r;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+          st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(sQ, row, ks, hh), kf[ks], st, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(sD, row, ks, hh), vf[ks], dp, 0, 0, 0);
+        }
+        // accumulator rows are query rows: q_local = qb32*32 + (e&3) + 8(e>>2) + 4hh ; column (lane) = key
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const int ql = qb32 * 32 + 8 * g4 + 4 * hh;
+          const f32x4_t l4 = *reinterpret_cast<const f32x4_t*>(sL + ql);
+          const f32x4_t d4 = *reinterpret_cast<const f32x4_t*>(sL + 64 + ql);
+#pragma unroll
+          for (int e2 = 0; e2 < 4; ++e2) {
+            const int e = 4 * g4 + e2;
+            const float lse = (l4[e2] == -INFINITY) ? 0.f : l4[e2];
+            float p = exp2f(st[e] * a.scale_log2 - lse);
+            if (cls != 2) {
+              const int qi = qt * DKV_QT + ql + e2;
+              bool ok = (qi < a.S) && (key < a.S) && (key <= qi || key < my_prefix);
+              if (a.doc_ids) ok = ok && (a.doc_ids[(int64_t)b * a.S + min(qi, a.S - 1)] == key_doc);
+              p = ok ? p : 0.f;
+            }
+            st[e] = p;                   // P
+            dp[e] = p * (dp[e] - d4[e2]);  // dS (unscaled)
+          }
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          bf16x8_t pb, dsb;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { pb[j] = (__bf16)st[8 * s + j]; dsb[j] = (__bf16)dp[8 * s + j]; }
+#pragma unroll
+          for (int db = 0; db < 4; ++db) {
+            dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(sD, qb32 * 32 + s * 16, db, lane), pb, dv[db], 0, 0, 0);
+            dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(sQ, qb32 * 32 + s * 16, db, lane), dsb, dk[db], 0, 0, 0);
+          }
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    cur ^= 1;
+    it = itn;
+  }
+
+  if (key < a.S) {
+    bf16_t* kp = a.dk + (int64_t)b * a.dk_sb + (int64_t)key * a.dk_ss + kvh * HD;
+    bf16_t* vp = a.dv + (int64_t)b * a.dv_sb + (int64_t)key * a.dv_ss + kvh * HD;
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        u32x2_t pk;
+        pk[0] = pack_bf2(dk[db][4 * g4 + 0] * a.scale, dk[db][4 * g4 + 1] * a.scale);
+        pk[1] = pack_bf2(dk[db][4 * g4 + 2] * a.scale, dk[db][4 * g4 + 3] * a.scale);
+        *reinterpret_cast<u32x2_t*>(kp + 32 * db + 8 * g4 + 4 * hh) = pk;
+        pk[0] = pack_bf2(dv[db][4 * g4 + 0], dv[db][4 * g4 + 1]);
+        pk[1] = pack_bf2(dv[db][4 * g4 + 2], dv[db][4 * g4 + 3]);
+        *reinterpret_cast<u32x2_t*>(vp + 32 * db + 8 * g4 + 4 * hh) = pk;
+      }
+  }
+}
+
+static bool g_bwd_attr = false;
+
+// delta: fp32 [B,H,S] workspace (written here).  All strides in elements.  flags as in llx_attn_fwd.
+extern "C" int llx_attn_bwd(const void* q, int64_t q_sb, int64_t q_ss, const void* k, int64_t k_sb, int64_t k_ss, const void* v,
+                            int64_t v_sb, int64_t v_ss, const void* o, int64_t o_sb, int64_t o_ss, const void* d_o, int64_t do_sb,
+                            int64_t do_ss, const float* lse, float* delta, void* dq, int64_t dq_sb, int64_t dq_ss, void* dk,
+                            int64_t dk_sb, int64_t dk_ss, void* dv, int64_t dv_sb, int64_t dv_ss, const int* doc_ids,
+                            const int* prefix_len, const void* flags, int64_t B, int64_t S, int64_t H, int64_t KVH, int64_t head_dim,
+                            float scale, hipStream_t stream) {
+  LLX_REQUIRE(q && k && v && o && d_o && lse && delta && dq && dk && dv, "llx_attn_bwd: null pointer");
+  LLX_REQUIRE(head_dim == HD, "llx_attn_bwd: head_dim=%lld unsupported (only 128)", (long long)head_dim);
+  LLX_REQUIRE(B > 0 && S > 0 && H > 0 && KVH > 0 && H % KVH == 0, "llx_attn_bwd: bad B/S/H/KVH");
+  LLX_REQUIRE(((q_ss | k_ss | v_ss | o_ss | do_ss | q_sb | k_sb | v_sb | o_sb | do_sb) % 8) == 0, "llx_attn_bwd: input strides must keep 16-byte alignment");
+  LLX_REQUIRE(((dq_ss | dk_ss | dv_ss | dq_sb | dk_sb | dv_sb) % 4) == 0, "llx_attn_bwd: output strides must keep 8-byte alignment");
+  LLX_REQUIRE(((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o | (uintptr_t)d_o) % 16 == 0, "llx_attn_bwd: unaligned input");
+  LLX_REQUIRE(((uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv) % 8 == 0, "llx_attn_bwd: unaligned output");
+  LLX_REQUIRE(!(doc_ids || prefix_len) || flags, "llx_attn_bwd: tile flags required with doc_ids/prefix_len");
+  if (!g_bwd_attr) {
+    hipError_t e1 = hipFuncSetAttribute((const void*)attn_bwd_dq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DQ_LDS_BYTES);
+    hipError_t e2 = hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS_BYTES);
+    if (e1 != hipSuccess || e2 != hipSuccess) { llx_set_error("llx_attn_bwd: cannot raise LDS limit"); return LLX_ERR_LAUNCH; }
+    g_bwd_attr = true;
+  }
+  AttnBwdArgs a;
+  a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.o = (const bf16_t*)o; a.d_o = (const bf16_t*)d_o;
+  a.lse = lse; a.delta = delta; a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk; a.dv = (bf16_t*)dv;
+  a.q_sb = q_sb; a.q_ss = q_ss; a.k_sb = k_sb; a.k_ss = k_ss; a.v_sb = v_sb; a.v_ss = v_ss; a.o_sb = o_sb; a.o_ss = o_ss;
+  a.do_sb = do_sb; a.do_ss = do_ss; a.dq_sb = dq_sb; a.dq_ss = dq_ss; a.dk_sb = dk_sb; a.dk_ss = dk_ss; a.dv_sb = dv_sb; a.dv_ss = dv_ss;
+  a.doc_ids = doc_ids; a.prefix_len = prefix_len; a.flags = (doc_ids || prefix_len) ? (const uint8_t*)flags : nullptr;
+  a.B = (int)B; a.S = (int)S; a.H = (int)H; a.KVH = (int)KVH;
+  a.scale = scale; a.scale_log2 = scale * 1.4426950408889634f;
+  const int64_t rows = B * S * H;
+  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)cdiv64(rows, 16)), dim3(256), 0, stream, a);
+  LLX_LAUNCH_CHECK("llx_attn_bwd(delta)");
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((unsigned)cdiv64(S, 128), (unsigned)KVH, (unsigned)B), dim3(256), DKV_LDS_BYTES, stream, a);
+  LLX_LAUNCH_CHECK("llx_attn_bwd(dkv)");
+  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((unsigned)cdiv64(S, BQ), (unsigned)H, (unsigned)B), dim3(256), DQ_LDS_BYTES, stream, a);
+  LLX_LAUNCH_CHECK("llx_attn_bwd(dq)");
+  return LLX_OK;
+}
