@@ -1,0 +1,280 @@
+// HBM-bound glue kernels of the layer: embedding gather, RoPE, SwiGLU, scaling, transposes, residual add.
+// All bf16 traffic is 16 B per lane (8 elements); math in fp32 with the reference's rounding points.
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------ embedding
+// nn.Embedding forward (modelling/llama.py:180,206; modelling/audio.py:49): out[t,:] = table[ids[t],:].
+// out rows may be strided (row stride out_ld) so the gather can land directly behind an audio prefix (audio.py:63).
+__global__ void embedding_fwd_kernel(const int64_t* __restrict__ ids, const bf16_t* __restrict__ table, bf16_t* __restrict__ out,
+                                     int64_t n_tok, int dim, int64_t vocab, int64_t tok_per_batch, int64_t out_sb, int64_t out_ss) {
+  const int64_t t = blockIdx.x;
+  int64_t id = ids[t];
+  id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);  // host validates; clamp keeps a bad id from faulting the GPU
+  const bf16_t* src = table + id * dim;
+  bf16_t* dst = out + (t / tok_per_batch) * out_sb + (t % tok_per_batch) * out_ss;
+  for (int c = threadIdx.x * 8; c < dim; c += blockDim.x * 8) *reinterpret_cast<u32x4_t*>(dst + c) = *reinterpret_cast<const u32x4_t*>(src + c);
+}
+
+extern "C" int llx_embedding_fwd(const int64_t* ids, const void* table, void* out, int64_t n_tok, int64_t dim, int64_t vocab,
+                                 int64_t tok_per_batch, int64_t out_sb, int64_t out_ss, hipStream_t stream) {
+  LLX_REQUIRE(ids && table && out, "llx_embedding_fwd: null pointer");
+  LLX_REQUIRE(dim % 8 == 0 && out_ss % 8 == 0 && out_sb % 8 == 0, "llx_embedding_fwd: dim/strides must be multiples of 8");
+  LLX_REQUIRE(tok_per_batch > 0 && vocab > 0, "llx_embedding_fwd: bad sizes");
+  if (n_tok == 0) return LLX_OK;
+  hipLaunchKernelGGL(embedding_fwd_kernel, dim3((unsigned)n_tok), dim3(256), 0, stream, ids, (const bf16_t*)table, (bf16_t*)out, n_tok,
+                     (int)dim, vocab, tok_per_batch, out_sb, out_ss);
+  LLX_LAUNCH_CHECK("llx_embedding_fwd");
+  return LLX_OK;
+}
+
+// Embedding weight gradient: dtable[ids[t],:] += dy[t,:] in fp32 (atomic adds of whole 256-B lane groups).
+__global__ void embedding_bwd_kernel(const int64_t* __restrict__ ids, const bf16_t* __restrict__ dy, float* __restrict__ dtable,
+                                     int64_t n_tok, int dim, int64_t vocab, int64_t tok_per_batch, int64_t dy_sb, int64_t dy_ss) {
+  const int64_t t = blockIdx.x;
+  const int64_t id = ids[t];
+  if (id < 0 || id >= vocab) return;
+  const bf16_t* src = dy + (t / tok_per_batch) * dy_sb + (t % tok_per_batch) * dy_ss;
+  float* dst = dtable + id * dim;
+  for (int c = threadIdx.x; c < dim; c += blockDim.x) atomicAdd(dst + c, bf2f(src[c]));
+}
+
+extern "C" int llx_embedding_bwd(const int64_t* ids, const void* dy, float* dtable_f32, int64_t n_tok, int64_t dim, int64_t vocab,
+                                 int64_t tok_per_batch, int64_t dy_sb, int64_t dy_ss, hipStream_t stream) {
+  LLX_REQUIRE(ids && dy && dtable_f32, "llx_embedding_bwd: null pointer");
+  if (n_tok == 0) return LLX_OK;
+  hipLaunchKernelGGL(embedding_bwd_kernel, dim3((unsigned)n_tok), dim3(256), 0, stream, ids, (const bf16_t*)dy, dtable_f32, n_tok, (int)dim,
+                     vocab, tok_per_batch, dy_sb, dy_ss);
+  LLX_LAUNCH_CHECK("llx_embedding_bwd");
+  return LLX_OK;
+}
+
+// ------------------------------------------------------------------------------------------ RoPE
+// apply_rope (modelling/llama.py:63-73): interleaved pairs (2i,2i+1), fp32 math, one rounding to bf16.
+// Works in place on the first `nheads` heads of every row of a [B,S,*] buffer (q heads then k heads of a fused
+// projection are contiguous).  sign=+1 forward, -1 backward (rotation by -theta is the exact transpose).
+__global__ void rope_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, const float* __restrict__ table, int64_t n_rows,
+                            int S, int nheads, int64_t x_sb, int64_t x_ss, int64_t y_sb, int64_t y_ss, float sign) {
+  // 16 threads per head (8 elements each); head_dim fixed 128
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int sub = (int)(gid & 15);
+  const int64_t hrow = gid >> 4;  // (b*S + s) * nheads + h
+  if (hrow >= n_rows * nheads) return;
+  const int h = (int)(hrow % nheads);
+  const int64_t bs = hrow / nheads;
+  const int s = (int)(bs % S);
+  const int64_t b = bs / S;
+  const u32x4_t v = *reinterpret_cast<const u32x4_t*>(x + b * x_sb + (int64_t)s * x_ss + h * 128 + sub * 8);
+  const float* tp = table + ((int64_t)s * 64 + sub * 4) * 2;
+  const f32x4_t t0 = *reinterpret_cast<const f32x4_t*>(tp);
+  const f32x4_t t1 = *reinterpret_cast<const f32x4_t*>(tp + 4);
+  const float cs[4] = {t0[0], t0[2], t1[0], t1[2]};
+  const float sn[4] = {t0[1] * sign, t0[3] * sign, t1[1] * sign, t1[3] * sign};
+  u32x4_t o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float x0 = bflo(v[e]), x1 = bfhi(v[e]);
+    o[e] = pack_bf2(x0 * cs[e] - x1 * sn[e], x1 * cs[e] + x0 * sn[e]);
+  }
+  *reinterpret_cast<u32x4_t*>(y + b * y_sb + (int64_t)s * y_ss + h * 128 + sub * 8) = o;
+}
+
+extern "C" int llx_rope(const void* x, int64_t x_sb, int64_t x_ss, void* y, int64_t y_sb, int64_t y_ss, const float* table, int64_t B,
+                        int64_t S, int64_t nheads, int64_t head_dim, int backward, hipStream_t stream) {
+  LLX_REQUIRE(x && y && table, "llx_rope: null pointer");
+  LLX_REQUIRE(head_dim == 128, "llx_rope: head_dim=%lld unsupported (only 128)", (long long)head_dim);
+  LLX_REQUIRE(((x_sb | x_ss | y_sb | y_ss) % 8) == 0, "llx_rope: strides must be multiples of 8 elements");
+  const int64_t n = B * S * nheads * 16;
+  if (n == 0) return LLX_OK;
+  hipLaunchKernelGGL(rope_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, stream, (const bf16_t*)x, (bf16_t*)y, table, B * S, (int)S,
+                     (int)nheads, x_sb, x_ss, y_sb, y_ss, backward ? -1.f : 1.f);
+  LLX_LAUNCH_CHECK("llx_rope");
+  return LLX_OK;
+}
+
+// ------------------------------------------------------------------------------------------ SwiGLU
+// silu(w1 x) * w3 x (modelling/llama.py:152) with eager rounding points: s = bf16(silu(g)); h = bf16(s * u).
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
+
+__global__ void swiglu_fwd_kernel(const bf16_t* __restrict__ g, const bf16_t* __restrict__ u, bf16_t* __restrict__ h, int64_t rows, int cols,
+                                  int64_t g_ld, int64_t u_ld, int64_t h_ld) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int cpr = cols >> 3;
+  if (idx >= rows * cpr) return;
+  const int64_t r = idx / cpr;
+  const int c = (int)(idx % cpr) * 8;
+  const u32x4_t gv = *reinterpret_cast<const u32x4_t*>(g + r * g_ld + c);
+  const u32x4_t uv = *reinterpret_cast<const u32x4_t*>(u + r * u_ld + c);
+  u32x4_t o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float g0 = bflo(gv[e]), g1 = bfhi(gv[e]);
+    const float s0 = bf2f(f2bf(g0 * sigmoidf_(g0))), s1 = bf2f(f2bf(g1 * sigmoidf_(g1)));
+    o[e] = pack_bf2(s0 * bflo(uv[e]), s1 * bfhi(uv[e]));
+  }
+  *reinterpret_cast<u32x4_t*>(h + r * h_ld + c) = o;
+}
+
+// dg = dh*u*silu'(g), du = dh*silu(g)
+__global__ void swiglu_bwd_kernel(const bf16_t* __restrict__ dh, const bf16_t* __restrict__ g, const bf16_t* __restrict__ u,
+                                  bf16_t* __restrict__ dg, bf16_t* __restrict__ du, int64_t rows, int cols, int64_t dh_ld, int64_t g_ld,
+                                  int64_t u_ld, int64_t dg_ld, int64_t du_ld) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int cpr = cols >> 3;
+  if (idx >= rows * cpr) return;
+  const int64_t r = idx / cpr;
+  const int c = (int)(idx % cpr) * 8;
+  const u32x4_t dv = *reinterpret_cast<const u32x4_t*>(dh + r * dh_ld + c);
+  const u32x4_t gv = *reinterpret_cast<const u32x4_t*>(g + r * g_ld + c);
+  const u32x4_t uv = *reinterpret_cast<const u32x4_t*>(u + r * u_ld + c);
+  u32x4_t og, ou;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float dgs[2], dus[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const float gg = p ? bfhi(gv[e]) : bflo(gv[e]);
+      const float uu = p ? bfhi(uv[e]) : bflo(uv[e]);
+      const float dd = p ? bfhi(dv[e]) : bflo(dv[e]);
+      const float sg = sigmoidf_(gg);
+      const float silu = bf2f(f2bf(gg * sg));
+      dus[p] = dd * silu;
+      const float ds = bf2f(f2bf(dd * uu));
+      dgs[p] = ds * (sg * (1.f + gg * (1.f - sg)));
+    }
+    og[e] = pack_bf2(dgs[0], dgs[1]);
+    ou[e] = pack_bf2(dus[0], dus[1]);
+  }
+  *reinterpret_cast<u32x4_t*>(dg + r * dg_ld + c) = og;
+  *reinterpret_cast<u32x4_t*>(du + r * du_ld + c) = ou;
+}
+
+extern "C" int llx_swiglu_fwd(const void* g, int64_t g_ld, const void* u, int64_t u_ld, void* h, int64_t h_ld, int64_t rows, int64_t cols,
+                              hipStream_t stream) {
+  LLX_REQUIRE(g && u && h, "llx_swiglu_fwd: null pointer");
+  LLX_REQUIRE(cols % 8 == 0 && ((g_ld | u_ld | h_ld) % 8) == 0, "llx_swiglu_fwd: cols/strides must be multiples of 8");
+  const int64_t n = rows * (cols / 8);
+  if (n == 0) return LLX_OK;
+  hipLaunchKernelGGL(swiglu_fwd_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, stream, (const bf16_t*)g, (const bf16_t*)u, (bf16_t*)h,
+                     rows, (int)cols, g_ld, u_ld, h_ld);
+  LLX_LAUNCH_CHECK("llx_swiglu_fwd");
+  return LLX_OK;
+}
+
+extern "C" int llx_swiglu_bwd(const void* dh, int64_t dh_ld, const void* g, int64_t g_ld, const void* u, int64_t u_ld, void* dg,
+                              int64_t dg_ld, void* du, int64_t du_ld, int64_t rows, int64_t cols, hipStream_t stream) {
+  LLX_REQUIRE(dh && g && u && dg && du, "llx_swiglu_bwd: null pointer");
+  LLX_REQUIRE(cols % 8 == 0 && ((dh_ld | g_ld | u_ld | dg_ld | du_ld) % 8) == 0, "llx_swiglu_bwd: cols/strides must be multiples of 8");
+  const int64_t n = rows * (cols / 8);
+  if (n == 0) return LLX_OK;
+  hipLaunchKernelGGL(swiglu_bwd_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, stream, (const bf16_t*)dh, (const bf16_t*)g,
+                     (const bf16_t*)u, (bf16_t*)dg, (bf16_t*)du, rows, (int)cols, dh_ld, g_ld, u_ld, dg_ld, du_ld);
+  LLX_LAUNCH_CHECK("llx_swiglu_bwd");
+  return LLX_OK;
+}
+
+// ------------------------------------------------------------------------------------------ small utilities
+// y = bf16(x * s) with s = *scalar (device fp32) * host_scale ; optional per-column bf16 scale (int8 backward: g * scale).
+__global__ void scale_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, const float* __restrict__ dev_scalar, float host_scale,
+                             const bf16_t* __restrict__ colscale, int64_t rows, int cols, int64_t x_ld, int64_t y_ld) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int cpr = cols >> 3;
+  if (idx >= rows * cpr) return;
+  const int64_t r = idx / cpr;
+  const int c = (int)(idx % cpr) * 8;
+  const float s = (dev_scalar ? *dev_scalar : 1.f) * host_scale;
+  const u32x4_t v = *reinterpret_cast<const u32x4_t*>(x + r * x_ld + c);
+  u32x4_t cs = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+  if (colscale) cs = *reinterpret_cast<const u32x4_t*>(colscale + c);
+  u32x4_t o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) o[e] = pack_bf2(bflo(v[e]) * s * bflo(cs[e]), bfhi(v[e]) * s * bfhi(cs[e]));
+  *reinterpret_cast<u32x4_t*>(y + r * y_ld + c) = o;
+}
+
+extern "C" int llx_scale(const void* x, int64_t x_ld, void* y, int64_t y_ld, const float* dev_scalar, float host_scale, const void* colscale,
+                         int64_t rows, int64_t cols, hipStream_t stream) {
+  LLX_REQUIRE(x && y, "llx_scale: null pointer");
+  LLX_REQUIRE(cols % 8 == 0 && ((x_ld | y_ld) % 8) == 0, "llx_scale: cols/strides must be multiples of 8");
+  const int64_t n = rows * (cols / 8);
+  if (n == 0) return LLX_OK;
+  hipLaunchKernelGGL(scale_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, stream, (const bf16_t*)x, (bf16_t*)y, dev_scalar, host_scale,
+                     (const bf16_t*)colscale, rows, (int)cols, x_ld, y_ld);
+  LLX_LAUNCH_CHECK("llx_scale");
+  return LLX_OK;
+}
+
+// z = bf16(x + y) (residual joins of the backward pass)
+__global__ void add_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ y, bf16_t* __restrict__ z, int64_t n8) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n8) return;
+  const u32x4_t a = reinterpret_cast<const u32x4_t*>(x)[i], b = reinterpret_cast<const u32x4_t*>(y)[i];
+  u32x4_t o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) o[e] = pack_bf2(bflo(a[e]) + bflo(b[e]), bfhi(a[e]) + bfhi(b[e]));
+  reinterpret_cast<u32x4_t*>(z)[i] = o;
+}
+
+extern "C" int llx_add(const void* x, const void* y, void* z, int64_t n, hipStream_t stream) {
+  LLX_REQUIRE(x && y && z && n % 8 == 0, "llx_add: null pointer or n not a multiple of 8");
+  if (n == 0) return LLX_OK;
+  hipLaunchKernelGGL(add_kernel, dim3((unsigned)cdiv64(n / 8, 256)), dim3(256), 0, stream, (const bf16_t*)x, (const bf16_t*)y, (bf16_t*)z, n / 8);
+  LLX_LAUNCH_CHECK("llx_add");
+  return LLX_OK;
+}
+
+// out[C,R] = in[R,C]^T for 2-byte elements (cached transposed copies of frozen weights for the dgrad GEMM).
+// src_is_i8: the source is int8 and is widened to bf16 on the way (weight-only int8 path; int8 is exact in bf16).
+template <bool I8>
+__global__ void transpose_kernel(const void* __restrict__ in, bf16_t* __restrict__ out, int R, int C, int64_t in_ld, int64_t out_ld) {
+  __shared__ bf16_t tile[64][66];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  for (int i = threadIdx.x; i < 64 * 64; i += blockDim.x) {
+    const int r = i >> 6, c = i & 63;
+    bf16_t v = 0;
+    if (r0 + r < R && c0 + c < C) {
+      if constexpr (I8) v = f2bf((float)reinterpret_cast<const int8_t*>(in)[(int64_t)(r0 + r) * in_ld + c0 + c]);
+      else v = reinterpret_cast<const bf16_t*>(in)[(int64_t)(r0 + r) * in_ld + c0 + c];
+    }
+    tile[r][c] = v;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 64 * 64; i += blockDim.x) {
+    const int c = i >> 6, r = i & 63;
+    if (r0 + r < R && c0 + c < C) out[(int64_t)(c0 + c) * out_ld + r0 + r] = tile[r][c];
+  }
+}
+
+extern "C" int llx_transpose(const void* in, int64_t in_ld, void* out, int64_t out_ld, int64_t R, int64_t C, int src_is_i8, hipStream_t stream) {
+  LLX_REQUIRE(in && out && R > 0 && C > 0, "llx_transpose: bad arguments");
+  const dim3 grid((unsigned)cdiv64(C, 64), (unsigned)cdiv64(R, 64));
+  if (src_is_i8) hipLaunchKernelGGL(transpose_kernel<true>, grid, dim3(256), 0, stream, in, (bf16_t*)out, (int)R, (int)C, in_ld, out_ld);
+  else hipLaunchKernelGGL(transpose_kernel<false>, grid, dim3(256), 0, stream, in, (bf16_t*)out, (int)R, (int)C, in_ld, out_ld);
+  LLX_LAUNCH_CHECK("llx_transpose");
+  return LLX_OK;
+}
+
+// int8 -> bf16 widening copy (same layout): bf16 image of a frozen int8 weight for the weight-only linear.
+__global__ void i8_to_bf16_kernel(const int8_t* __restrict__ in, bf16_t* __restrict__ out, int64_t n) {
+  const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+  if (i >= n) return;
+  if (i + 8 <= n) {
+    const u32x2_t v = *reinterpret_cast<const u32x2_t*>(in + i);
+    u32x4_t o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const uint32_t w = v[e >> 1] >> ((e & 1) * 16);
+      o[e] = pack_bf2((float)(int8_t)(w & 0xff), (float)(int8_t)((w >> 8) & 0xff));
+    }
+    *reinterpret_cast<u32x4_t*>(out + i) = o;
+  } else {
+    for (int64_t j = i; j < n; ++j) out[j] = f2bf((float)in[j]);
+  }
+}
+
+extern "C" int llx_i8_to_bf16(const void* in, void* out, int64_t n, hipStream_t stream) {
+  LLX_REQUIRE(in && out && ((uintptr_t)in % 8) == 0 && ((uintptr_t)out % 16) == 0, "llx_i8_to_bf16: null/unaligned pointer");
+  if (n == 0) return LLX_OK;
+  hipLaunchKernelGGL(i8_to_bf16_kernel, dim3((unsigned)cdiv64(cdiv64(n, 8), 256)), dim3(256), 0, stream, (const int8_t*)in, (bf16_t*)out, n);
+  LLX_LAUNCH_CHECK("llx_i8_to_bf16");
+  return LLX_OK;
+}

@@ -1,0 +1,194 @@
+// Skinny contractions of the LoRA adapter (modelling/lora.py:40-44 and its autograd):
+//   skinny_nt :  T[M, 64pad] = X[M,K] . W[R,K]^T            (x @ lora_a^T ; dy @ lora_b with lora_b^T given)
+//   skinny_tn :  G[R, N]     = s * U[M, R]^T . Y[M, N]       (d lora_a = s * u^T x ; d lora_b^T = s * t^T dy)
+// Both are HBM-bound on the big operand (X or Y, read once); R <= 64 rides on 16x16x32 MFMA tiles.
+#include "common.h"
+
+typedef __attribute__((address_space(3))) s16x4_t lds_s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+
+#define SK_PAD 64  // skinny outputs are [M, 64] bf16, columns >= R are zero (they feed the GEMM K-extension)
+
+// ------------------------------------------------------------------------------------------ NT
+// block = 4 waves = 16 rows of X; the waves interleave over k-steps of 32 and combine through LDS.
+template <int NB>
+__global__ __launch_bounds__(256) void skinny_nt_kernel(const bf16_t* __restrict__ X, int64_t ldx, const bf16_t* __restrict__ W, int64_t ldw,
+                                                        bf16_t* __restrict__ out, int M, int K, int R) {
+  __shared__ float part[4][16][SK_PAD];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int m0 = blockIdx.x * 16;
+  const int fr = lane & 15, fq = lane >> 4;
+  const bf16_t* xp = X + (int64_t)min(m0 + fr, M - 1) * ldx + 8 * fq;
+  const bf16_t* wp[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) wp[nb] = W + (int64_t)min(nb * 16 + fr, R - 1) * ldw + 8 * fq;
+  f32x4_t acc[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) acc[nb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const int nks = K >> 5;
+#pragma unroll 4
+  for (int ks = wave; ks < nks; ks += 4) {
+    const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(xp + ks * 32);
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      const bf16x8_t b = *reinterpret_cast<const bf16x8_t*>(wp[nb] + ks * 32);
+      acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[nb], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) part[wave][fq * 4 + e][nb * 16 + fr] = acc[nb][e];
+  __syncthreads();
+  // thread t -> row t>>4, cols (t&15)*4..+4
+  const int row = threadIdx.x >> 4, c0 = (threadIdx.x & 15) * 4;
+  if (m0 + row < M) {
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int c = c0 + e;
+      v[e] = (c < NB * 16 && c < R) ? part[0][row][c] + part[1][row][c] + part[2][row][c] + part[3][row][c] : 0.f;
+    }
+    u32x2_t pk = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+    *reinterpret_cast<u32x2_t*>(out + (int64_t)(m0 + row) * SK_PAD + c0) = pk;
+  }
+}
+
+// out: [M, 64] bf16 (row stride 64). K % 32 == 0, R <= 64.
+extern "C" int llx_skinny_nt(const void* X, int64_t ldx, const void* W, int64_t ldw, void* out, int64_t M, int64_t K, int64_t R,
+                             hipStream_t stream) {
+  LLX_REQUIRE(X && W && out, "llx_skinny_nt: null pointer");
+  LLX_REQUIRE(M > 0 && K > 0 && K % 32 == 0 && R > 0 && R <= 64, "llx_skinny_nt: need K%%32==0 and 0<R<=64 (K=%lld R=%lld)", (long long)K, (long long)R);
+  LLX_REQUIRE(ldx % 8 == 0 && ldw % 8 == 0 && ((uintptr_t)X | (uintptr_t)W) % 16 == 0 && (uintptr_t)out % 8 == 0, "llx_skinny_nt: alignment");
+  const dim3 grid((unsigned)cdiv64(M, 16)), block(256);
+  const int nb = (int)cdiv64(R, 16);
+#define L(N) hipLaunchKernelGGL(skinny_nt_kernel<N>, grid, block, 0, stream, (const bf16_t*)X, ldx, (const bf16_t*)W, ldw, (bf16_t*)out, (int)M, (int)K, (int)R)
+  if (nb == 1) L(1); else if (nb == 2) L(2); else L(4);
+#undef L
+  LLX_LAUNCH_CHECK("llx_skinny_nt");
+  return LLX_OK;
+}
+
+// ------------------------------------------------------------------------------------------ TN
+#define TN_NT 256                 // columns of Y per block
+#define TN_MS 32                  // rows per step
+#define TN_YROW (TN_NT * 2 + 16)  // padded LDS row strides (bytes)
+#define TN_UROW (SK_PAD * 2 + 16)
+
+// 16x16x32 operand (k = 8*(lane>>4)+j, index = lane&15) read transposed from a [32 rows][cols] bf16 LDS tile:
+// element j = tile[8*(lane>>4) + j][c0 + (lane&15)].
+__device__ __forceinline__ bf16x8_t tr16_frag(const char* tile, int rowbytes, int c0, int lane) {
+  const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+  const char* base = tile + (8 * g + q) * rowbytes + (c0 + 4 * p) * 2;
+  s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)base);
+  s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + 4 * rowbytes));
+  s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8_t, v);
+}
+
+template <int NB>
+__global__ __launch_bounds__(256) void skinny_tn_kernel(const bf16_t* __restrict__ U, const bf16_t* __restrict__ Y, int64_t ldy,
+                                                        float* __restrict__ partial, int M, int N, int rows_per_split) {
+  __shared__ __attribute__((aligned(16))) char sY[TN_MS * TN_YROW];
+  __shared__ __attribute__((aligned(16))) char sU[TN_MS * TN_UROW];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n0 = blockIdx.x * TN_NT;
+  const int split = blockIdx.y;
+  const int m_begin = split * rows_per_split, m_end = min(M, m_begin + rows_per_split);
+  f32x4_t acc[NB][4];
+#pragma unroll
+  for (int rb = 0; rb < NB; ++rb)
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) acc[rb][cb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  for (int ms = m_begin; ms < m_end; ms += TN_MS) {
+    // global -> registers (zero rows past the end / columns past N)
+    u32x4_t yv[4], uv;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int q = i * 256 + tid;  // chunk of 16 B: row q>>5, chunk q&31
+      const int row = ms + (q >> 5), col = n0 + (q & 31) * 8;
+      yv[i] = (row < m_end && col < N) ? *reinterpret_cast<const u32x4_t*>(Y + (int64_t)row * ldy + col) : u32x4_t{0u, 0u, 0u, 0u};
+    }
+    {
+      const int row = ms + (tid >> 3);
+      uv = (row < m_end) ? *reinterpret_cast<const u32x4_t*>(U + (int64_t)row * SK_PAD + (tid & 7) * 8) : u32x4_t{0u, 0u, 0u, 0u};
+    }
+    __syncthreads();  // previous step's reads are done
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int q = i * 256 + tid;
+      *reinterpret_cast<u32x4_t*>(sY + (q >> 5) * TN_YROW + (q & 31) * 16) = yv[i];
+    }
+    *reinterpret_cast<u32x4_t*>(sU + (tid >> 3) * TN_UROW + (tid & 7) * 16) = uv;
+    __syncthreads();
+    bf16x8_t a[NB];
+#pragma unroll
+    for (int rb = 0; rb < NB; ++rb) a[rb] = tr16_frag(sU, TN_UROW, rb * 16, lane);
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+      const bf16x8_t b = tr16_frag(sY, TN_YROW, wave * 64 + cb * 16, lane);
+#pragma unroll
+      for (int rb = 0; rb < NB; ++rb) acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[rb], b, acc[rb][cb], 0, 0, 0);
+    }
+  }
+  // D[row = r][col = n]: lane -> n = lane&15, r = (lane>>4)*4 + e
+  const int fr = lane & 15, fq = lane >> 4;
+#pragma unroll
+  for (int rb = 0; rb < NB; ++rb)
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+      const int n = n0 + wave * 64 + cb * 16 + fr;
+      if (n < N) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) partial[((int64_t)split * (NB * 16) + rb * 16 + fq * 4 + e) * N + n] = acc[rb][cb][e];
+      }
+    }
+}
+
+// out = bf16(scale * sum_split partial[split][r][n] (+ out));  transpose_out: out is [N, R] (ld = out_ld) else [R, N].
+__global__ void skinny_tn_reduce_kernel(const float* __restrict__ partial, bf16_t* __restrict__ out, int64_t out_ld, int nsplit, int RP, int R,
+                                        int N, float scale, int transpose_out, int accumulate) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)R * N) return;
+  const int r = (int)(idx / N), n = (int)(idx % N);
+  float s = 0.f;
+  for (int p = 0; p < nsplit; ++p) s += partial[((int64_t)p * RP + r) * N + n];
+  s *= scale;
+  bf16_t* dst = transpose_out ? out + (int64_t)n * out_ld + r : out + (int64_t)r * out_ld + n;
+  if (accumulate) s += bf2f(*dst);
+  *dst = f2bf(s);
+}
+
+static int tn_splits(int64_t M, int64_t N) {
+  const int64_t ntiles = cdiv64(N, TN_NT);
+  int64_t want = cdiv64(512, ntiles);           // ~2 blocks per CU
+  const int64_t max_split = cdiv64(M, 4 * TN_MS);  // at least 4 steps per block
+  if (want > max_split) want = max_split;
+  if (want < 1) want = 1;
+  return (int)want;
+}
+
+extern "C" int64_t llx_skinny_tn_workspace_bytes(int64_t M, int64_t N, int64_t R) {
+  return (int64_t)tn_splits(M, N) * cdiv64(R, 16) * 16 * N * 4;
+}
+
+// U: [M, 64] bf16 (row stride 64; columns >= R ignored), Y: [M, N] (row stride ldy).  workspace as above.
+extern "C" int llx_skinny_tn(const void* U, const void* Y, int64_t ldy, void* out, int64_t out_ld, int64_t M, int64_t N, int64_t R,
+                             float scale, int transpose_out, int accumulate, void* workspace, hipStream_t stream) {
+  LLX_REQUIRE(U && Y && out && workspace, "llx_skinny_tn: null pointer");
+  LLX_REQUIRE(M > 0 && N > 0 && N % 8 == 0 && R > 0 && R <= 64 && ldy % 8 == 0, "llx_skinny_tn: need N%%8==0, ldy%%8==0, 0<R<=64");
+  LLX_REQUIRE(((uintptr_t)U | (uintptr_t)Y) % 16 == 0, "llx_skinny_tn: unaligned pointer");
+  const int nsplit = tn_splits(M, N);
+  int rows_per_split = (int)cdiv64(cdiv64(M, nsplit), TN_MS) * TN_MS;
+  const int nb = (int)cdiv64(R, 16);
+  const dim3 grid((unsigned)cdiv64(N, TN_NT), (unsigned)nsplit), block(256);
+#define L(NBV) hipLaunchKernelGGL(skinny_tn_kernel<NBV>, grid, block, 0, stream, (const bf16_t*)U, (const bf16_t*)Y, ldy, (float*)workspace, (int)M, (int)N, rows_per_split)
+  if (nb == 1) L(1); else if (nb == 2) L(2); else if (nb == 3) L(3); else L(4);
+#undef L
+  LLX_LAUNCH_CHECK("llx_skinny_tn");
+  hipLaunchKernelGGL(skinny_tn_reduce_kernel, dim3((unsigned)cdiv64(R * N, 256)), dim3(256), 0, stream, (const float*)workspace, (bf16_t*)out,
+                     out_ld, nsplit, nb * 16, (int)R, (int)N, scale, transpose_out, accumulate);
+  LLX_LAUNCH_CHECK("llx_skinny_tn(reduce)");
+  return LLX_OK;
+}

@@ -30,6 +30,20 @@ SIGNATURES: dict[str, tuple] = {
     "llx_attn_fwd": (c_int, [_P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _P, _P, _P, _L, _L, _L, _L, _L, _F, _P]),
     "llx_attn_bwd": (c_int, [_P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _P, _P, _L, _L, _P, _L, _L, _P, _L, _L,
                              _P, _P, _P, _L, _L, _L, _L, _L, _F, _P]),
+    "llx_embedding_fwd": (c_int, [_P, _P, _P, _L, _L, _L, _L, _L, _L, _P]),
+    "llx_embedding_bwd": (c_int, [_P, _P, _P, _L, _L, _L, _L, _L, _L, _P]),
+    "llx_rope": (c_int, [_P, _L, _L, _P, _L, _L, _P, _L, _L, _L, _L, _I, _P]),
+    "llx_swiglu_fwd": (c_int, [_P, _L, _P, _L, _P, _L, _L, _L, _P]),
+    "llx_swiglu_bwd": (c_int, [_P, _L, _P, _L, _P, _L, _P, _L, _P, _L, _L, _L, _P]),
+    "llx_scale": (c_int, [_P, _L, _P, _L, _P, _F, _P, _L, _L, _P]),
+    "llx_add": (c_int, [_P, _P, _P, _L, _P]),
+    "llx_transpose": (c_int, [_P, _L, _P, _L, _L, _L, _I, _P]),
+    "llx_i8_to_bf16": (c_int, [_P, _P, _L, _P]),
+    "llx_ce_workspace_bytes": (c_int64, [_L]),
+    "llx_ce_fwd_bwd": (c_int, [_P, _L, _P, _L, _P, _P, _P, _L, _L, _P]),
+    "llx_skinny_nt": (c_int, [_P, _L, _P, _L, _P, _L, _L, _L, _P]),
+    "llx_skinny_tn_workspace_bytes": (c_int64, [_L, _L, _L]),
+    "llx_skinny_tn": (c_int, [_P, _P, _L, _P, _L, _L, _L, _L, _F, _I, _I, _P, _P]),
     "llx_gemm_nt_bf16": (c_int, [_P, _L, _P, _L, _P, _L, _L, _L, _L, _P, _L, _P, _L, _L, _I, _P, _L, _P]),
 }
 

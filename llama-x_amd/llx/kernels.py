@@ -1,0 +1,318 @@
+"""Functional (non-autograd) wrappers over the C-ABI: shape/dtype checks in Python, raw pointers below.
+
+Every function launches on torch's current HIP stream and returns torch tensors it allocated through
+torch's caching allocator; the C side never allocates or synchronises (include/llx.h).
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+from torch import Tensor
+
+from . import _lib as L
+
+BF16 = torch.bfloat16
+EPI_NONE, EPI_RESIDUAL, EPI_BIAS, EPI_BIAS_GELU, EPI_COLSCALE = 0, 1, 2, 3, 4
+SK_PAD = 64
+
+
+def _lib():
+    return L.load()
+
+
+def _rows2d(x: Tensor) -> Tensor:
+    """View [..., C] as [R, C] with a single row stride (no copy when the leading dims are jointly contiguous)."""
+    if x.dim() == 2:
+        return x if x.stride(1) == 1 else x.contiguous()
+    y = x.reshape(-1, x.shape[-1])
+    return y if y.stride(1) == 1 else y.contiguous()
+
+
+def _chk_bf16(*ts):
+    for t in ts:
+        if t is not None:
+            assert t.dtype is BF16, f"llx kernels compute in bf16 (got {t.dtype})"
+    L.require_cuda(*ts)
+
+
+# ------------------------------------------------------------------------------------------------- rmsnorm
+def rmsnorm_fwd(x: Tensor, w: Tensor, eps: float) -> tuple[Tensor, Tensor]:
+    _chk_bf16(x, w)
+    x2 = _rows2d(x)
+    assert x2.stride(0) == x2.shape[1], "rmsnorm input rows must be dense"
+    rows, dim = x2.shape
+    assert w.shape == (dim,) and w.is_contiguous()
+    y = torch.empty_like(x2)
+    rstd = torch.empty(rows, device=x.device, dtype=torch.float32)
+    L.check(_lib().llx_rmsnorm_fwd(L.ptr(x2), L.ptr(w), L.ptr(y), L.ptr(rstd), rows, dim, eps, L.stream()), "llx_rmsnorm_fwd")
+    return y.view(x.shape), rstd
+
+
+def rmsnorm_bwd(dy: Tensor, x: Tensor, w: Tensor, rstd: Tensor, need_dw: bool) -> tuple[Tensor, Optional[Tensor]]:
+    _chk_bf16(dy, x, w)
+    x2, dy2 = _rows2d(x), _rows2d(dy)
+    if dy2.stride(0) != dy2.shape[1]:
+        dy2 = dy2.contiguous()
+    rows, dim = x2.shape
+    dx = torch.empty_like(x2)
+    dw = ws = None
+    if need_dw:
+        dw = torch.empty(dim, device=x.device, dtype=BF16)
+        ws = torch.empty(_lib().llx_rmsnorm_bwd_workspace_bytes(rows, dim), device=x.device, dtype=torch.uint8)
+    L.check(_lib().llx_rmsnorm_bwd(L.ptr(dy2), L.ptr(x2), L.ptr(w), L.ptr(rstd), L.ptr(dx), L.ptr(dw), 0, L.ptr(ws), rows, dim, L.stream()),
+            "llx_rmsnorm_bwd")
+    return dx.view(x.shape), dw
+
+
+# ------------------------------------------------------------------------------------------------- gemm
+def gemm_nt(a: Tensor, b: Tensor, *, out: Optional[Tensor] = None, a2: Optional[Tensor] = None, b2: Optional[Tensor] = None,
+            epilogue: int = EPI_NONE, e: Optional[Tensor] = None) -> Tensor:
+    """out[M,N] = a[M,K] @ b[N,K]^T (+ a2[M,K2] @ b2[N,K2]^T) with a fused epilogue; bf16, fp32 accumulate."""
+    _chk_bf16(a, b, a2, b2, e, out)
+    assert a.dim() == 2 and b.dim() == 2 and a.shape[1] == b.shape[1], (a.shape, b.shape)
+    assert a.stride(1) == 1 and b.stride(1) == 1
+    M, K = a.shape
+    N = b.shape[0]
+    if out is None:
+        out = torch.empty(M, N, device=a.device, dtype=BF16)
+    assert out.shape == (M, N) and out.stride(1) == 1
+    K2 = 0
+    if a2 is not None:
+        assert b2 is not None and a2.shape[0] == M and b2.shape[0] == N and a2.shape[1] == b2.shape[1]
+        assert a2.stride(1) == 1 and b2.stride(1) == 1
+        K2 = a2.shape[1]
+    lde = 0
+    if epilogue == EPI_RESIDUAL:
+        assert e is not None and e.shape == (M, N) and e.stride(1) == 1
+        lde = e.stride(0)
+    elif epilogue != EPI_NONE:
+        assert e is not None and e.shape == (N,) and e.is_contiguous()
+    L.check(_lib().llx_gemm_nt_bf16(L.ptr(a), a.stride(0), L.ptr(b), b.stride(0), L.ptr(out), out.stride(0), M, N, K,
+                                    L.ptr(a2), a2.stride(0) if a2 is not None else 0, L.ptr(b2), b2.stride(0) if b2 is not None else 0, K2,
+                                    epilogue, L.ptr(e), lde, L.stream()), "llx_gemm_nt_bf16")
+    return out
+
+
+def transpose(x: Tensor) -> Tensor:
+    """[R,C] -> [C,R] bf16 copy; an int8 source is widened to bf16 on the way."""
+    L.require_cuda(x)
+    assert x.dim() == 2 and x.stride(1) == 1 and x.dtype in (BF16, torch.int8)
+    R, C = x.shape
+    out = torch.empty(C, R, device=x.device, dtype=BF16)
+    L.check(_lib().llx_transpose(L.ptr(x), x.stride(0), L.ptr(out), R, R, C, int(x.dtype is torch.int8), L.stream()), "llx_transpose")
+    return out
+
+
+def i8_to_bf16(x: Tensor) -> Tensor:
+    L.require_cuda(x)
+    assert x.dtype is torch.int8 and x.is_contiguous()
+    out = torch.empty(x.shape, device=x.device, dtype=BF16)
+    L.check(_lib().llx_i8_to_bf16(L.ptr(x), L.ptr(out), x.numel(), L.stream()), "llx_i8_to_bf16")
+    return out
+
+
+def scale(x: Tensor, *, dev_scalar: Optional[Tensor] = None, host_scale: float = 1.0, colscale: Optional[Tensor] = None,
+          out: Optional[Tensor] = None) -> Tensor:
+    _chk_bf16(x, colscale, out)
+    x2 = _rows2d(x)
+    rows, cols = x2.shape
+    if out is None:
+        out = torch.empty(rows, cols, device=x.device, dtype=BF16)
+    o2 = _rows2d(out)
+    if dev_scalar is not None:
+        assert dev_scalar.dtype is torch.float32 and dev_scalar.numel() == 1
+    L.check(_lib().llx_scale(L.ptr(x2), x2.stride(0), L.ptr(o2), o2.stride(0), L.ptr(dev_scalar), host_scale, L.ptr(colscale), rows, cols,
+                             L.stream()), "llx_scale")
+    return out.view(x.shape) if out.numel() == x.numel() else out
+
+
+def add(x: Tensor, y: Tensor) -> Tensor:
+    _chk_bf16(x, y)
+    assert x.shape == y.shape
+    x, y = x.contiguous(), y.contiguous()
+    z = torch.empty_like(x)
+    L.check(_lib().llx_add(L.ptr(x), L.ptr(y), L.ptr(z), x.numel(), L.stream()), "llx_add")
+    return z
+
+
+# ------------------------------------------------------------------------------------------------- embedding
+def embedding_fwd(ids: Tensor, table: Tensor, out: Optional[Tensor] = None) -> Tensor:
+    """out[b, s, :] = table[ids[b, s], :]; ``out`` may be a strided [B, S, D] view (e.g. behind an audio prefix)."""
+    _chk_bf16(table)
+    L.require_cuda(ids)
+    assert ids.dtype is torch.int64 and ids.dim() == 2
+    ids = ids.contiguous()
+    B, S = ids.shape
+    V, D = table.shape
+    assert table.is_contiguous()
+    if out is None:
+        out = torch.empty(B, S, D, device=table.device, dtype=BF16)
+    assert out.shape == (B, S, D) and out.stride(2) == 1
+    L.check(_lib().llx_embedding_fwd(L.ptr(ids), L.ptr(table), L.ptr(out), B * S, D, V, S, out.stride(0), out.stride(1), L.stream()),
+            "llx_embedding_fwd")
+    return out
+
+
+def embedding_bwd(ids: Tensor, dy: Tensor, vocab: int) -> Tensor:
+    """fp32 [V, D] gradient of the table."""
+    _chk_bf16(dy)
+    ids = ids.contiguous()
+    B, S = ids.shape
+    D = dy.shape[-1]
+    assert dy.shape == (B, S, D) and dy.stride(2) == 1
+    dt = torch.zeros(vocab, D, device=dy.device, dtype=torch.float32)
+    L.check(_lib().llx_embedding_bwd(L.ptr(ids), L.ptr(dy), L.ptr(dt), B * S, D, vocab, S, dy.stride(0), dy.stride(1), L.stream()),
+            "llx_embedding_bwd")
+    return dt
+
+
+# ------------------------------------------------------------------------------------------------- rope
+def rope_(x: Tensor, table: Tensor, nheads: int, backward: bool = False) -> Tensor:
+    """In-place interleaved-pair rotation of the first ``nheads`` 128-wide heads of every row of x [B, S, *]."""
+    _chk_bf16(x)
+    assert x.dim() == 3 and x.stride(2) == 1 and x.shape[2] >= nheads * 128
+    assert table.dtype is torch.float32 and table.is_contiguous() and table.shape[0] >= x.shape[1] and table.shape[1:] == (64, 2)
+    B, S, _ = x.shape
+    L.check(_lib().llx_rope(L.ptr(x), x.stride(0), x.stride(1), L.ptr(x), x.stride(0), x.stride(1), L.ptr(table), B, S, nheads, 128,
+                            int(backward), L.stream()), "llx_rope")
+    return x
+
+
+# ------------------------------------------------------------------------------------------------- swiglu
+def swiglu_fwd(g: Tensor, u: Tensor) -> Tensor:
+    _chk_bf16(g, u)
+    assert g.shape == u.shape and g.dim() == 2 and g.stride(1) == 1 and u.stride(1) == 1
+    rows, cols = g.shape
+    h = torch.empty(rows, cols, device=g.device, dtype=BF16)
+    L.check(_lib().llx_swiglu_fwd(L.ptr(g), g.stride(0), L.ptr(u), u.stride(0), L.ptr(h), cols, rows, cols, L.stream()), "llx_swiglu_fwd")
+    return h
+
+
+def swiglu_bwd(dh: Tensor, g: Tensor, u: Tensor, dg: Tensor, du: Tensor) -> None:
+    _chk_bf16(dh, g, u, dg, du)
+    rows, cols = g.shape
+    for t in (dh, g, u, dg, du):
+        assert t.shape == (rows, cols) and t.stride(1) == 1
+    L.check(_lib().llx_swiglu_bwd(L.ptr(dh), dh.stride(0), L.ptr(g), g.stride(0), L.ptr(u), u.stride(0), L.ptr(dg), dg.stride(0), L.ptr(du),
+                                  du.stride(0), rows, cols, L.stream()), "llx_swiglu_bwd")
+
+
+# ------------------------------------------------------------------------------------------------- attention
+class MaskSpec:
+    """Per-token mask metadata (replaces FlexAttention's BlockMask in the ``block_mask=`` slot).
+
+    allow(q, k) = (k <= q or k < prefix_len[b]) and (doc_ids is None or doc_ids[b, q] == doc_ids[b, k]).
+    ``doc_ids`` int32 [B, S] (or [S], broadcast), ``prefix_len`` int32 [B].  Tile classes are built once on device.
+    """
+
+    def __init__(self, doc_ids: Optional[Tensor] = None, prefix_len: Optional[Tensor] = None):
+        self.doc_ids = doc_ids
+        self.prefix_len = prefix_len
+        self._flags = None
+        self._key = None
+
+    def prepared(self, B: int, S: int, device) -> "MaskSpec":
+        key = (B, S, str(device))
+        if self._key == key:
+            return self
+        d = self.doc_ids
+        if d is not None:
+            d = d.to(device=device, dtype=torch.int32)
+            if d.dim() == 1:
+                d = d.view(1, -1)
+            assert d.shape[1] == S
+            d = d.expand(B, S).contiguous()
+        p = self.prefix_len
+        if p is not None:
+            p = torch.as_tensor(p, device=device).to(torch.int32).reshape(-1)
+            if p.numel() == 1:
+                p = p.expand(B)
+            assert p.numel() == B
+            p = p.contiguous()
+        self.doc_ids, self.prefix_len = d, p
+        self._flags = None
+        if d is not None or p is not None:
+            fl = torch.empty(_lib().llx_attn_flags_bytes(B, S), device=device, dtype=torch.uint8)
+            L.check(_lib().llx_attn_tile_flags(L.ptr(d), L.ptr(p), L.ptr(fl), B, S, L.stream()), "llx_attn_tile_flags")
+            self._flags = fl
+        self._key = key
+        return self
+
+
+def attn_fwd(q: Tensor, k: Tensor, v: Tensor, mask: Optional[MaskSpec] = None) -> tuple[Tensor, Tensor]:
+    """q [B,S,H,128], k/v [B,S,KVH,128] (last two dims dense; batch/seq strides free) -> o [B,S,H,128], lse [B,H,S]."""
+    _chk_bf16(q, k, v)
+    B, S, H, hd = q.shape
+    KVH = k.shape[2]
+    for t in (q, k, v):
+        assert t.stride(3) == 1 and t.stride(2) == hd
+    o = torch.empty(B, S, H, hd, device=q.device, dtype=BF16)
+    lse = torch.empty(B, H, S, device=q.device, dtype=torch.float32)
+    d = p = fl = None
+    if mask is not None:
+        mask = mask.prepared(B, S, q.device)
+        d, p, fl = mask.doc_ids, mask.prefix_len, mask._flags
+    L.check(_lib().llx_attn_fwd(L.ptr(q), q.stride(0), q.stride(1), L.ptr(k), k.stride(0), k.stride(1), L.ptr(v), v.stride(0), v.stride(1),
+                                L.ptr(o), o.stride(0), o.stride(1), L.ptr(lse), L.ptr(d), L.ptr(p), L.ptr(fl), B, S, H, KVH, hd,
+                                1.0 / math.sqrt(hd), L.stream()), "llx_attn_fwd")
+    return o, lse
+
+
+def attn_bwd(q: Tensor, k: Tensor, v: Tensor, o: Tensor, do: Tensor, lse: Tensor, dq: Tensor, dk: Tensor, dv: Tensor,
+             mask: Optional[MaskSpec] = None) -> None:
+    _chk_bf16(q, k, v, o, do, dq, dk, dv)
+    B, S, H, hd = q.shape
+    KVH = k.shape[2]
+    for t in (q, k, v, o, do, dq, dk, dv):
+        assert t.stride(3) == 1 and t.stride(2) == hd
+    delta = torch.empty(B, H, S, device=q.device, dtype=torch.float32)
+    d = p = fl = None
+    if mask is not None:
+        mask = mask.prepared(B, S, q.device)
+        d, p, fl = mask.doc_ids, mask.prefix_len, mask._flags
+    L.check(_lib().llx_attn_bwd(L.ptr(q), q.stride(0), q.stride(1), L.ptr(k), k.stride(0), k.stride(1), L.ptr(v), v.stride(0), v.stride(1),
+                                L.ptr(o), o.stride(0), o.stride(1), L.ptr(do), do.stride(0), do.stride(1), L.ptr(lse), L.ptr(delta),
+                                L.ptr(dq), dq.stride(0), dq.stride(1), L.ptr(dk), dk.stride(0), dk.stride(1), L.ptr(dv), dv.stride(0),
+                                dv.stride(1), L.ptr(d), L.ptr(p), L.ptr(fl), B, S, H, KVH, hd, 1.0 / math.sqrt(hd), L.stream()), "llx_attn_bwd")
+
+
+# ------------------------------------------------------------------------------------------------- cross entropy
+def ce_fwd_bwd(logits: Tensor, labels: Tensor, write_grad: bool) -> tuple[Tensor, Optional[Tensor]]:
+    """Mean CE over labels != -100.  With write_grad the logits buffer is overwritten by d loss / d logits."""
+    _chk_bf16(logits)
+    L.require_cuda(labels)
+    lg = _rows2d(logits)
+    T, V = lg.shape
+    labels = labels.reshape(-1).contiguous()
+    assert labels.dtype is torch.int64 and labels.numel() == T
+    loss = torch.empty((), device=logits.device, dtype=torch.float32)
+    ws = torch.empty(_lib().llx_ce_workspace_bytes(T), device=logits.device, dtype=torch.uint8)
+    L.check(_lib().llx_ce_fwd_bwd(L.ptr(lg), lg.stride(0), L.ptr(lg) if write_grad else None, lg.stride(0), L.ptr(labels), L.ptr(loss),
+                                  L.ptr(ws), T, V, L.stream()), "llx_ce_fwd_bwd")
+    return loss, (lg if write_grad else None)
+
+
+# ------------------------------------------------------------------------------------------------- skinny (LoRA)
+def skinny_nt(x: Tensor, w: Tensor) -> Tensor:
+    """[M,K] @ [R,K]^T -> [M,64] bf16, zero beyond column R."""
+    _chk_bf16(x, w)
+    assert x.dim() == 2 and w.dim() == 2 and x.shape[1] == w.shape[1] and x.stride(1) == 1 and w.stride(1) == 1
+    M, K = x.shape
+    R = w.shape[0]
+    out = torch.empty(M, SK_PAD, device=x.device, dtype=BF16)
+    L.check(_lib().llx_skinny_nt(L.ptr(x), x.stride(0), L.ptr(w), w.stride(0), L.ptr(out), M, K, R, L.stream()), "llx_skinny_nt")
+    return out
+
+
+def skinny_tn(u: Tensor, y: Tensor, R: int, scale_: float, out: Tensor, transpose_out: bool, accumulate: bool = False) -> Tensor:
+    """out ([R,N], or [N,R] when transpose_out) (+)= scale * u[:, :R]^T @ y, u [M,64], y [M,N]."""
+    _chk_bf16(u, y, out)
+    M, N = y.shape
+    assert u.shape == (M, SK_PAD) and u.is_contiguous() and y.stride(1) == 1 and out.stride(1) == 1
+    assert out.shape == ((N, R) if transpose_out else (R, N))
+    ws = torch.empty(_lib().llx_skinny_tn_workspace_bytes(M, N, R), device=y.device, dtype=torch.uint8)
+    L.check(_lib().llx_skinny_tn(L.ptr(u), L.ptr(y), y.stride(0), L.ptr(out), out.stride(0), M, N, R, scale_, int(transpose_out),
+                                 int(accumulate), L.ptr(ws), L.stream()), "llx_skinny_tn")
+    return out
