@@ -278,3 +278,22 @@ extern "C" int llx_i8_to_bf16(const void* in, void* out, int64_t n, hipStream_t 
   LLX_LAUNCH_CHECK("llx_i8_to_bf16");
   return LLX_OK;
 }
+
+// out[R, 64] = bf16(scale * src) zero-padded to 64 columns; src is [R, C] (transpose=0) or [C, R] (transpose=1).
+// Builds the K-extension operands of the LoRA-fused GEMM (s*lora_b -> [out,64]; s*lora_a^T -> [in,64]).
+__global__ void pad64_kernel(const bf16_t* __restrict__ in, int64_t ld, bf16_t* __restrict__ out, int R, int C, float scale, int transpose) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)R * 64) return;
+  const int r = (int)(idx >> 6), c = (int)(idx & 63);
+  float v = 0.f;
+  if (c < C) v = bf2f(transpose ? in[(int64_t)c * ld + r] : in[(int64_t)r * ld + c]) * scale;
+  out[idx] = f2bf(v);
+}
+
+extern "C" int llx_pad64(const void* in, int64_t ld, void* out, int64_t R, int64_t C, float scale, int transpose, hipStream_t stream) {
+  LLX_REQUIRE(in && out && R > 0 && C > 0 && C <= 64, "llx_pad64: bad arguments (C=%lld)", (long long)C);
+  hipLaunchKernelGGL(pad64_kernel, dim3((unsigned)cdiv64(R * 64, 256)), dim3(256), 0, stream, (const bf16_t*)in, ld, (bf16_t*)out, (int)R, (int)C,
+                     scale, transpose);
+  LLX_LAUNCH_CHECK("llx_pad64");
+  return LLX_OK;
+}

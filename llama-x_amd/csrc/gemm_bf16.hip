@@ -11,6 +11,7 @@
 // to the ds_read_b128 address.  The accumulators hold C^T fragments (mfma(B,A)), so each lane owns 4
 // consecutive output columns; the epilogue stages the bf16 tile through LDS and stores whole 512-B rows.
 #include "common.h"
+#include <type_traits>
 
 #define BM 256
 #define BN 256
@@ -37,8 +38,12 @@ typedef const __attribute__((address_space(1))) void gbl_void;
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
-template <int EPI>
-__global__ __launch_bounds__(512, 2) void gemm_nt_bf16_kernel(const GemmArgs g) {
+// I8 = true: A/B are int8 (K counted in int8 elements, 128 per tile row = the same 128-byte rows), MFMA is
+// v_mfma_i32_16x16x64_i8 with int32 accumulators, epilogue EPI_ROWCOLSCALE (torchao::int8_mm_dequant).
+template <int EPI, bool I8>
+__global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const GemmArgs g) {
+  constexpr int ESZ = I8 ? 1 : 2;         // bytes per element
+  constexpr int TK = 128 / ESZ;           // elements per 128-byte tile row (64 bf16 | 128 int8)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -70,23 +75,23 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_kernel(const GemmArgs g) 
     arow[i] = min(m0 + i * 64 + srow, g.M - 1);  // clamp: edge rows re-read a valid row, never stored
     brow[i] = min(n0 + i * 64 + srow, g.N - 1);
   }
-  const int nk1 = g.K / BK;
-  const int nk = nk1 + g.K2 / BK;
+  const int nk1 = g.K / TK;
+  const int nk = nk1 + g.K2 / TK;
 
   auto stage = [&](int buf, int kt) {
     char* sA = smem + buf * STAGE_BYTES;
     char* sB = sA + A_TILE_BYTES;
-    const bf16_t* Ap; const bf16_t* Bp; int64_t la, lb; int k0;
-    if (kt < nk1) { Ap = g.A; Bp = g.B; la = g.lda; lb = g.ldb; k0 = kt * BK; }
-    else { Ap = g.A2; Bp = g.B2; la = g.lda2; lb = g.ldb2; k0 = (kt - nk1) * BK; }
+    const char* Ap; const char* Bp; int64_t la, lb; int k0;  // byte pointers / byte strides / byte offset
+    if (kt < nk1) { Ap = (const char*)g.A; Bp = (const char*)g.B; la = g.lda * ESZ; lb = g.ldb * ESZ; k0 = kt * 128; }
+    else { Ap = (const char*)g.A2; Bp = (const char*)g.B2; la = g.lda2 * ESZ; lb = g.ldb2 * ESZ; k0 = (kt - nk1) * 128; }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const bf16_t* src = Ap + (int64_t)arow[i] * la + k0 + schunk * 8;
+      const char* src = Ap + (int64_t)arow[i] * la + k0 + schunk * 16;
       __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(sA + (i * 512 + wave * 64) * 16), 16, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const bf16_t* src = Bp + (int64_t)brow[i] * lb + k0 + schunk * 8;
+      const char* src = Bp + (int64_t)brow[i] * lb + k0 + schunk * 16;
       __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(sB + (i * 512 + wave * 64) * 16), 16, 0, 0);
     }
   };
@@ -100,11 +105,12 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_kernel(const GemmArgs g) 
   const int slot0 = ((0 * 4 + fq) ^ fsw) * 16;
   const int slot1 = ((1 * 4 + fq) ^ fsw) * 16;
 
-  f32x4_t acc[8][4];
+  using acc_t = typename std::conditional<I8, i32x4_t, f32x4_t>::type;
+  acc_t acc[8][4];
 #pragma unroll
   for (int i = 0; i < 8; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < 4; ++j) acc[i][j] = acc_t{0, 0, 0, 0};
 
   stage(0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -118,16 +124,22 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_kernel(const GemmArgs g) 
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int slot = ks ? slot1 : slot0;
-      bf16x8_t af[8], bfr[4];
+      // 16-byte fragments: 8 bf16 (k = 8*(lane>>4)+j) or 16 int8 (k = 16*(lane>>4)+j) -- same bytes, same addresses
+      i32x4_t af[8], bfr[4];
 #pragma unroll
-      for (int ni = 0; ni < 4; ++ni) bfr[ni] = *reinterpret_cast<const bf16x8_t*>(sB + b_base + ni * 16 * 128 + slot);
+      for (int ni = 0; ni < 4; ++ni) bfr[ni] = *reinterpret_cast<const i32x4_t*>(sB + b_base + ni * 16 * 128 + slot);
 #pragma unroll
-      for (int mi = 0; mi < 8; ++mi) af[mi] = *reinterpret_cast<const bf16x8_t*>(sA + a_base + mi * 16 * 128 + slot);
+      for (int mi = 0; mi < 8; ++mi) af[mi] = *reinterpret_cast<const i32x4_t*>(sA + a_base + mi * 16 * 128 + slot);
 #pragma unroll
       for (int mi = 0; mi < 8; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ni], af[mi], acc[mi][ni], 0, 0, 0);
+        for (int ni = 0; ni < 4; ++ni) {
+          if constexpr (I8)
+            acc[mi][ni] = __builtin_amdgcn_mfma_i32_16x16x64_i8(bfr[ni], af[mi], acc[mi][ni], 0, 0, 0);
+          else
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, bfr[ni]), __builtin_bit_cast(bf16x8_t, af[mi]),
+                                                                  acc[mi][ni], 0, 0, 0);
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -137,12 +149,23 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_kernel(const GemmArgs g) 
 #pragma unroll
   for (int mi = 0; mi < 8; ++mi) {
     const int m = wm * 128 + mi * 16 + frow;
+    float rs = 1.f;
+    if constexpr (I8) rs = bf2f(g.E2[min(m0 + m, g.M - 1)]);  // A_scale_rowwise[m]
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
       const int n = wn * 64 + ni * 16 + fq * 4;
+      float c[4];
+      if constexpr (I8) {
+        // acc.to(fp32) * a_scale * b_scale, one rounding to the scale dtype (subclasses/int8_mm.py:112-118)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) c[e] = ((float)acc[mi][ni][e] * rs) * bf2f(g.E[min(n0 + n + e, g.N - 1)]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) c[e] = acc[mi][ni][e];
+      }
       u32x2_t pk;
-      pk[0] = pack_bf2(acc[mi][ni][0], acc[mi][ni][1]);
-      pk[1] = pack_bf2(acc[mi][ni][2], acc[mi][ni][3]);
+      pk[0] = pack_bf2(c[0], c[1]);
+      pk[1] = pack_bf2(c[2], c[3]);
       *reinterpret_cast<u32x2_t*>(smem + m * EPI_ROW_BYTES + n * 2) = pk;
     }
   }
@@ -183,9 +206,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_kernel(const GemmArgs g) 
 
 static bool g_attr_set[8] = {false};
 
-template <int EPI>
+template <int EPI, bool I8 = false>
 static int launch_gemm(const GemmArgs& a, hipStream_t stream) {
-  auto kern = gemm_nt_bf16_kernel<EPI>;
+  auto kern = gemm_nt_kernel<EPI, I8>;
   if (!g_attr_set[EPI]) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
     if (e != hipSuccess) {
@@ -230,4 +253,24 @@ extern "C" int llx_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64
     case EPI_COLSCALE: return launch_gemm<EPI_COLSCALE>(a, stream);
     default: llx_set_error("llx_gemm_nt_bf16: unknown epilogue %d", epilogue); return LLX_ERR_UNSUPPORTED;
   }
+}
+
+// torchao::int8_mm_dequant (subclasses/int8_mm.py:121-149): C[M,N] = (A_i8[M,K] . B_i8[N,K]^T)_int32 * a_scale[m] * b_scale[n]
+// rounded once to bf16.  B is passed K-contiguous, i.e. the reference's B = int_data.T (strides (1,K)) IS this layout.
+// K must be a multiple of 128; scales bf16.
+extern "C" int llx_int8_mm_dequant(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M, int64_t N,
+                                   int64_t K, const void* a_scale, const void* b_scale, hipStream_t stream) {
+  LLX_REQUIRE(A && B && C && a_scale && b_scale, "llx_int8_mm_dequant: null pointer");
+  LLX_REQUIRE(M > 0 && N > 0 && K > 0, "llx_int8_mm_dequant: empty problem");
+  LLX_REQUIRE(K % 128 == 0, "llx_int8_mm_dequant: K=%lld must be a multiple of 128", (long long)K);
+  LLX_REQUIRE(N % 8 == 0 && ldc % 8 == 0, "llx_int8_mm_dequant: N and ldc must be multiples of 8");
+  LLX_REQUIRE(lda % 16 == 0 && ldb % 16 == 0, "llx_int8_mm_dequant: int8 row strides must be multiples of 16");
+  LLX_REQUIRE(((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) % 16 == 0, "llx_int8_mm_dequant: pointers must be 16-byte aligned");
+  GemmArgs a;
+  a.A = (const bf16_t*)A; a.B = (const bf16_t*)B; a.C = (bf16_t*)C; a.A2 = nullptr; a.B2 = nullptr;
+  a.E = (const bf16_t*)b_scale; a.E2 = (const bf16_t*)a_scale;
+  a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.lde = 0; a.lda2 = 0; a.ldb2 = 0;
+  a.M = (int)M; a.N = (int)N; a.K = (int)K; a.K2 = 0;
+  a.grid_m = (int)cdiv64(M, BM); a.grid_n = (int)cdiv64(N, BN);
+  return launch_gemm<EPI_ROWCOLSCALE, true>(a, stream);
 }

@@ -95,14 +95,31 @@ def gemm_nt(a: Tensor, b: Tensor, *, out: Optional[Tensor] = None, a2: Optional[
     return out
 
 
-def transpose(x: Tensor) -> Tensor:
-    """[R,C] -> [C,R] bf16 copy; an int8 source is widened to bf16 on the way."""
+def transpose(x: Tensor, pad_to: int = 1) -> Tensor:
+    """[R,C] -> [C,Rp] bf16 copy (Rp = R rounded up to ``pad_to``, zero filled); int8 sources are widened to bf16."""
     L.require_cuda(x)
     assert x.dim() == 2 and x.stride(1) == 1 and x.dtype in (BF16, torch.int8)
     R, C = x.shape
-    out = torch.empty(C, R, device=x.device, dtype=BF16)
-    L.check(_lib().llx_transpose(L.ptr(x), x.stride(0), L.ptr(out), R, R, C, int(x.dtype is torch.int8), L.stream()), "llx_transpose")
+    Rp = (R + pad_to - 1) // pad_to * pad_to
+    out = (torch.zeros if Rp != R else torch.empty)(C, Rp, device=x.device, dtype=BF16)
+    L.check(_lib().llx_transpose(L.ptr(x), x.stride(0), L.ptr(out), Rp, R, C, int(x.dtype is torch.int8), L.stream()), "llx_transpose")
     return out
+
+
+def pad64(x: Tensor, scale_: float = 1.0, transposed: bool = False) -> Tensor:
+    """[R,C<=64] -> [R,64] (or, transposed, [C<=64,R] -> [R,64]) bf16(scale*x), zero padded."""
+    _chk_bf16(x)
+    assert x.dim() == 2 and x.stride(1) == 1
+    R, C = (x.shape[1], x.shape[0]) if transposed else x.shape
+    out = torch.empty(R, SK_PAD, device=x.device, dtype=BF16)
+    L.check(_lib().llx_pad64(L.ptr(x), x.stride(0), L.ptr(out), R, C, scale_, int(transposed), L.stream()), "llx_pad64")
+    return out
+
+
+def gemm_tn(a: Tensor, b: Tensor) -> Tensor:
+    """a[M,N1]^T @ b[M,N2] -> [N1,N2] (weight gradients): transposed, zero-padded copies feed the NT kernel."""
+    at, bt = transpose(a, 64), transpose(b, 64)
+    return gemm_nt(at, bt)
 
 
 def i8_to_bf16(x: Tensor) -> Tensor:
@@ -125,16 +142,37 @@ def scale(x: Tensor, *, dev_scalar: Optional[Tensor] = None, host_scale: float =
         assert dev_scalar.dtype is torch.float32 and dev_scalar.numel() == 1
     L.check(_lib().llx_scale(L.ptr(x2), x2.stride(0), L.ptr(o2), o2.stride(0), L.ptr(dev_scalar), host_scale, L.ptr(colscale), rows, cols,
                              L.stream()), "llx_scale")
-    return out.view(x.shape) if out.numel() == x.numel() else out
+    return out.view(x.shape) if (out.is_contiguous() and out.numel() == x.numel()) else out
 
 
-def add(x: Tensor, y: Tensor) -> Tensor:
-    _chk_bf16(x, y)
+def add(x: Tensor, y: Tensor, out: Optional[Tensor] = None) -> Tensor:
+    _chk_bf16(x, y, out)
     assert x.shape == y.shape
     x, y = x.contiguous(), y.contiguous()
-    z = torch.empty_like(x)
+    z = out if (out is not None and out.is_contiguous()) else torch.empty_like(x)
     L.check(_lib().llx_add(L.ptr(x), L.ptr(y), L.ptr(z), x.numel(), L.stream()), "llx_add")
+    if out is not None and z is not out:
+        scale(z, out=out)  # strided destination: one more pass through the strided copy kernel
+        return out
     return z
+
+
+_ONES: dict = {}
+
+
+def colsum(dy: Tensor) -> Tensor:
+    """Column sums of [M,N] -> [N] (bias gradients), as a rank-1 skinny_tn against a column of ones."""
+    M, N = dy.shape
+    key = (M, str(dy.device))
+    ones = _ONES.get(key)
+    if ones is None:
+        ones = torch.zeros(M, SK_PAD, device=dy.device, dtype=BF16)
+        ones[:, 0] = 1
+        _ONES.clear()
+        _ONES[key] = ones
+    out = torch.empty(1, N, device=dy.device, dtype=BF16)
+    skinny_tn(ones, dy, 1, 1.0, out, transpose_out=False)
+    return out.view(N)
 
 
 # ------------------------------------------------------------------------------------------------- embedding

@@ -1,0 +1,407 @@
+"""Autograd layer over the HIP kernels: per-linear plans (dense / LoRA / int8) and fused block functions.
+
+One ``torch.autograd.Function`` per residual branch keeps the host-side graph small (2 nodes per transformer
+layer) and lets the forward write q|k|v and gate|up into fused buffers that the attention / SwiGLU kernels
+read through strides.  Frozen base weights get a cached transposed copy (HBM is 288 GB; a second 16 GB image
+of Llama-3.1-8B is cheap) so that every data-gradient is the same tuned NT GEMM as the forward.
+
+Reference semantics reproduced here: modelling/llama.py:108-174,196-219 ; modelling/lora.py:40-44 ;
+subclasses/int8.py:106-130.
+"""
+from __future__ import annotations
+
+from typing import Optional, Sequence
+
+import torch
+from torch import Tensor, nn
+from torch.autograd import Function
+
+from . import kernels as K
+from ._lib import LlxError
+
+BF16 = torch.bfloat16
+
+
+# =================================================================================================
+# cached derived images of (mostly frozen) weights
+# =================================================================================================
+def _cached(t: Tensor, tag: str, build):
+    """Cache ``build()`` on the tensor object, keyed by its version counter (in-place updates invalidate)."""
+    store = t.__dict__.setdefault("_llx_cache", {})
+    ver = t._version
+    hit = store.get(tag)
+    if hit is not None and hit[0] == ver and hit[1].device == t.device:
+        return hit[1]
+    val = build()
+    store[tag] = (ver, val)
+    return val
+
+
+def weight_t(w: Tensor) -> Tensor:
+    """[N,K] -> cached [K,N] bf16 image (B operand of the dgrad GEMM)."""
+    return _cached(w, "wt", lambda: K.transpose(w.detach()))
+
+
+# =================================================================================================
+# LinearPlan: how one nn.Linear (possibly LoRA-dressed, possibly int8) runs forward / backward
+# =================================================================================================
+class LinearPlan:
+    """Execution plan of one ``nn.Linear`` child as the reference would run it:
+
+    * plain:      F.linear(x, W, b)                                              (modelling/llama.py:118-120 ...)
+    * LoRA:       F.linear(x, W, b) + x @ A^T @ B^T * (alpha/r)                  (modelling/lora.py:40-44)
+    * int8 W:     _Int8Linear (weight-only or dynamic-activation)                (subclasses/int8.py:106-130)
+
+    ``tensors()`` lists the tensors autograd must see; ``backward`` returns their gradients in that order.
+    """
+
+    def __init__(self, m: nn.Linear):
+        from subclasses.int8 import Int8LinearWeight  # local import: subclasses imports llx too
+
+        self.N, self.K = m.out_features, m.in_features
+        self.weight = m.weight
+        self.bias = m.bias
+        self.rank = int(getattr(m, "rank", 0) or 0)
+        self.lora_a = getattr(m, "lora_a", None) if self.rank > 0 else None
+        self.lora_b = getattr(m, "lora_b", None) if self.rank > 0 else None
+        self.scale = float(getattr(m, "scale", 1.0))
+        self.dora_m = getattr(m, "m", None) if self.rank > 0 else None
+        if self.dora_m is not None:
+            raise LlxError("DoRALinear inside a fused block is not supported yet; use LoRA (modelling/lora.py:47-62 is second priority)")
+        self.int8 = isinstance(self.weight, Int8LinearWeight)
+        self.dynamic = bool(self.int8 and self.weight.dynamic_int8_act)
+        if self.rank > 64:
+            raise LlxError(f"LoRA rank {self.rank} > 64 is not supported by the skinny kernels")
+        if self.rank > 0 and self.lora_a.dtype is not BF16:
+            raise LlxError("LoRA factors must be bf16")
+
+    # ---- autograd-visible tensors
+    def tensors(self) -> list[Tensor]:
+        ts = []
+        if not self.int8:
+            ts.append(self.weight)
+        if self.bias is not None:
+            ts.append(self.bias)
+        if self.rank > 0:
+            ts += [self.lora_a, self.lora_b]
+        return ts
+
+    # ---- forward: y = linear(x) [+ residual]; returns (y, saved) where saved is the LoRA intermediate t = x @ A^T
+    def forward(self, x: Tensor, out: Optional[Tensor] = None, residual: Optional[Tensor] = None, gelu: bool = False):
+        t = b2 = None
+        if self.rank > 0:
+            t = K.skinny_nt(x, self.lora_a.detach())
+            b2 = K.pad64(self.lora_b.detach(), self.scale)
+        if self.int8:
+            from subclasses.int8 import int8_linear_forward
+
+            if self.bias is not None or gelu:
+                raise LlxError("int8 linear with bias is not on the fused path")
+            # (x @ W8^T) * scale is rounded to bf16 first (subclasses/int8.py:118); adapter and residual are added after
+            direct = self.rank == 0 and residual is None
+            y = int8_linear_forward(x, self.weight, out=out if direct else None)
+            if self.rank > 0:
+                y = K.gemm_nt(t, b2, out=out if residual is None else None, epilogue=K.EPI_RESIDUAL, e=y)
+            if residual is not None:
+                y = K.add(y, residual, out=out)
+            return y, t
+        w = self.weight.detach()
+        if self.bias is not None:
+            if residual is not None:
+                raise LlxError("bias + residual epilogue is not supported")
+            y = K.gemm_nt(x, w, out=out, a2=t, b2=b2, epilogue=K.EPI_BIAS_GELU if gelu else K.EPI_BIAS, e=self.bias.detach())
+        elif residual is not None:
+            y = K.gemm_nt(x, w, out=out, a2=t, b2=b2, epilogue=K.EPI_RESIDUAL, e=residual)
+        else:
+            y = K.gemm_nt(x, w, out=out, a2=t, b2=b2)
+        return y, t
+
+    # ---- backward: grads of tensors() and (optionally) dx (accumulated into dx_out when dx_accum)
+    def backward(self, dy: Tensor, x: Tensor, t: Optional[Tensor], needs: Sequence[bool], need_dx: bool = True,
+                 dx_out: Optional[Tensor] = None, dx_accum: bool = False):
+        grads: list[Optional[Tensor]] = []
+        ni = iter(needs)
+        u = None
+        if self.rank > 0:
+            u = K.skinny_nt(dy, K.transpose(self.lora_b.detach()))  # dy @ B  -> [M,64]
+        # --- parameter gradients, in tensors() order
+        if not self.int8:
+            grads.append(K.gemm_tn(dy, x) if next(ni) else None)
+        if self.bias is not None:
+            grads.append(K.colsum(dy) if next(ni) else None)
+        if self.rank > 0:
+            need_a, need_b = next(ni), next(ni)
+            ga = gb = None
+            if need_a:
+                ga = torch.empty(self.rank, self.K, device=dy.device, dtype=BF16)
+                K.skinny_tn(u, x, self.rank, self.scale, ga, transpose_out=False)
+            if need_b:
+                gb = torch.empty(self.N, self.rank, device=dy.device, dtype=BF16)
+                K.skinny_tn(t, dy, self.rank, self.scale, gb, transpose_out=True)
+            grads += [ga, gb]
+        # --- data gradient
+        dx = None
+        if need_dx:
+            b2 = K.pad64(self.lora_a.detach(), self.scale, transposed=True) if self.rank > 0 else None
+            if self.int8:
+                from subclasses.int8 import int8_weight_t
+
+                g = K.scale(dy, colscale=self.weight.scale)  # (g * scale) rounded to bf16 (subclasses/int8.py:127)
+                wt = int8_weight_t(self.weight)
+            else:
+                g = dy
+                wt = weight_t(self.weight)
+            if dx_accum:
+                dx = K.gemm_nt(g, wt, out=dx_out, a2=u, b2=b2, epilogue=K.EPI_RESIDUAL, e=dx_out)
+            else:
+                dx = K.gemm_nt(g, wt, out=dx_out, a2=u, b2=b2)
+        return dx, grads
+
+
+def _plans_tensors(plans: Sequence[LinearPlan]) -> tuple[list[Tensor], list[int]]:
+    ts, counts = [], []
+    for p in plans:
+        t = p.tensors()
+        ts += t
+        counts.append(len(t))
+    return ts, counts
+
+
+# =================================================================================================
+# generic single-linear function (LM head without labels, stand-alone LoRALinear / int8 F.linear)
+# =================================================================================================
+class LinearFn(Function):
+    @staticmethod
+    def forward(ctx, x: Tensor, plan: LinearPlan, *tensors):
+        K.L.require_cuda(x)
+        x2 = K._rows2d(x)
+        y, t = plan.forward(x2)
+        ctx.plan, ctx.t = plan, t
+        ctx.x2 = x2
+        ctx.xshape = x.shape
+        return y.view(*x.shape[:-1], plan.N)
+
+    @staticmethod
+    def backward(ctx, dy: Tensor):
+        plan: LinearPlan = ctx.plan
+        dy2 = K._rows2d(dy)
+        needs = ctx.needs_input_grad[2:]
+        dx, grads = plan.backward(dy2, ctx.x2, ctx.t, needs, need_dx=ctx.needs_input_grad[0])
+        return (dx.view(ctx.xshape) if dx is not None else None, None, *grads)
+
+
+def linear(x: Tensor, m: nn.Linear) -> Tensor:
+    plan = LinearPlan(m)
+    return LinearFn.apply(x, plan, *plan.tensors())
+
+
+def linear_lora_nobias(x: Tensor, m: nn.Linear) -> Tensor:
+    """F.linear(x, W) + LoRA term without the bias and without the DoRA rescale (DoRALinear composes the rest)."""
+    plan = LinearPlan.__new__(LinearPlan)
+    saved_m, saved_b = m.__dict__.get("_parameters", {}).get("m"), m.bias
+    try:
+        if saved_m is not None:
+            del m._parameters["m"]
+        m._parameters["bias"] = None
+        plan.__init__(m)
+    finally:
+        m._parameters["bias"] = saved_b
+        if saved_m is not None:
+            m._parameters["m"] = saved_m
+    return LinearFn.apply(x, plan, *plan.tensors())
+
+
+# =================================================================================================
+# RMSNorm
+# =================================================================================================
+class RMSNormFn(Function):
+    @staticmethod
+    def forward(ctx, x: Tensor, w: Tensor, eps: float):
+        y, rstd = K.rmsnorm_fwd(x.contiguous(), w.detach(), eps)
+        ctx.save_for_backward(x, w)
+        ctx.rstd = rstd
+        return y
+
+    @staticmethod
+    def backward(ctx, dy: Tensor):
+        x, w = ctx.saved_tensors
+        dx, dw = K.rmsnorm_bwd(dy.contiguous(), x.contiguous(), w.detach(), ctx.rstd, ctx.needs_input_grad[1])
+        return dx, dw, None
+
+
+def rmsnorm(x: Tensor, w: Tensor, eps: float) -> Tensor:
+    return RMSNormFn.apply(x, w, eps)
+
+
+# =================================================================================================
+# attention residual branch:  [x +] wo( attn( rope(wq xn), rope(wk xn), wv xn ) ),  xn = [rmsnorm(x)]
+# =================================================================================================
+class AttnBlockMeta:
+    def __init__(self, plans, num_heads, num_kv_heads, head_dim, mask, eps, fuse_norm, fuse_residual):
+        self.wq, self.wk, self.wv, self.wo = plans
+        self.H, self.KVH, self.hd = num_heads, num_kv_heads, head_dim
+        self.mask, self.eps = mask, eps
+        self.fuse_norm, self.fuse_residual = fuse_norm, fuse_residual
+
+
+class AttnBlockFn(Function):
+    @staticmethod
+    def forward(ctx, x: Tensor, rope: Tensor, norm_w: Optional[Tensor], meta: AttnBlockMeta, *tensors):
+        K.L.require_cuda(x)
+        B, S, D = x.shape
+        H, KVH, hd = meta.H, meta.KVH, meta.hd
+        x2 = K._rows2d(x.contiguous())
+        if meta.fuse_norm:
+            xn, rstd = K.rmsnorm_fwd(x2, norm_w.detach(), meta.eps)
+        else:
+            xn, rstd = x2, None
+        W = (H + 2 * KVH) * hd
+        qkv = torch.empty(B * S, W, device=x.device, dtype=BF16)
+        _, tq = meta.wq.forward(xn, out=qkv[:, : H * hd])
+        _, tk = meta.wk.forward(xn, out=qkv[:, H * hd : (H + KVH) * hd])
+        _, tv = meta.wv.forward(xn, out=qkv[:, (H + KVH) * hd :])
+        qkv3 = qkv.view(B, S, W)
+        K.rope_(qkv3, rope, H + KVH)
+        q = qkv3[..., : H * hd].unflatten(-1, (H, hd))
+        k = qkv3[..., H * hd : (H + KVH) * hd].unflatten(-1, (KVH, hd))
+        v = qkv3[..., (H + KVH) * hd :].unflatten(-1, (KVH, hd))
+        o, lse = K.attn_fwd(q, k, v, meta.mask)
+        o2 = o.view(B * S, H * hd)
+        y, to = meta.wo.forward(o2, residual=x2 if meta.fuse_residual else None)
+        ctx.meta = meta
+        ctx.save_for_backward(x, rope, norm_w)
+        ctx.saved = (x2, xn, rstd, qkv3, o, lse, tq, tk, tv, to)
+        return y.view(B, S, D)
+
+    @staticmethod
+    def backward(ctx, dy: Tensor):
+        meta: AttnBlockMeta = ctx.meta
+        x, rope, norm_w = ctx.saved_tensors
+        x2, xn, rstd, qkv3, o, lse, tq, tk, tv, to = ctx.saved
+        B, S, D = x.shape
+        H, KVH, hd = meta.H, meta.KVH, meta.hd
+        dy2 = K._rows2d(dy.contiguous())
+        needs = list(ctx.needs_input_grad[4:])
+        counts = [len(p.tensors()) for p in (meta.wq, meta.wk, meta.wv, meta.wo)]
+        nq, nk, nv, no = (needs[sum(counts[:i]) : sum(counts[: i + 1])] for i in range(4))
+        # wo
+        do2, g_o = meta.wo.backward(dy2, o.view(B * S, H * hd), to, no)
+        # attention
+        W = (H + 2 * KVH) * hd
+        dqkv = torch.empty(B, S, W, device=x.device, dtype=BF16)
+        q = qkv3[..., : H * hd].unflatten(-1, (H, hd))
+        k = qkv3[..., H * hd : (H + KVH) * hd].unflatten(-1, (KVH, hd))
+        v = qkv3[..., (H + KVH) * hd :].unflatten(-1, (KVH, hd))
+        dq = dqkv[..., : H * hd].unflatten(-1, (H, hd))
+        dk = dqkv[..., H * hd : (H + KVH) * hd].unflatten(-1, (KVH, hd))
+        dv = dqkv[..., (H + KVH) * hd :].unflatten(-1, (KVH, hd))
+        K.attn_bwd(q, k, v, o, do2.view(B, S, H, hd), lse, dq, dk, dv, meta.mask)
+        K.rope_(dqkv, rope, H + KVH, backward=True)
+        d2 = dqkv.view(B * S, W)
+        need_dx = ctx.needs_input_grad[0]
+        need_dxn = need_dx or (meta.fuse_norm and ctx.needs_input_grad[2])  # the norm weight gradient needs d(xn) too
+        dxn = torch.empty(B * S, D, device=x.device, dtype=BF16) if need_dxn else None
+        _, g_q = meta.wq.backward(d2[:, : H * hd], xn, tq, nq, need_dxn, dxn, False)
+        _, g_k = meta.wk.backward(d2[:, H * hd : (H + KVH) * hd], xn, tk, nk, need_dxn, dxn, True)
+        _, g_v = meta.wv.backward(d2[:, (H + KVH) * hd :], xn, tv, nv, need_dxn, dxn, True)
+        dx = dnw = None
+        if meta.fuse_norm:
+            if need_dxn:
+                dx, dnw = K.rmsnorm_bwd(dxn, x2, norm_w.detach(), rstd, ctx.needs_input_grad[2])
+        else:
+            dx = dxn
+        if need_dx and meta.fuse_residual:
+            dx = K.add(dx, dy2)
+        return (dx.view(B, S, D) if (dx is not None and need_dx) else None, None, dnw, None, *g_q, *g_k, *g_v, *g_o)
+
+
+# =================================================================================================
+# MLP residual branch:  [x +] w2( silu(w1 xn) * w3 xn ),  xn = [rmsnorm(x)]
+# =================================================================================================
+class MLPBlockMeta:
+    def __init__(self, plans, eps, fuse_norm, fuse_residual):
+        self.w1, self.w3, self.w2 = plans
+        self.eps, self.fuse_norm, self.fuse_residual = eps, fuse_norm, fuse_residual
+
+
+class MLPBlockFn(Function):
+    @staticmethod
+    def forward(ctx, x: Tensor, norm_w: Optional[Tensor], meta: MLPBlockMeta, *tensors):
+        K.L.require_cuda(x)
+        shape = x.shape
+        x2 = K._rows2d(x.contiguous())
+        if meta.fuse_norm:
+            xn, rstd = K.rmsnorm_fwd(x2, norm_w.detach(), meta.eps)
+        else:
+            xn, rstd = x2, None
+        T, I = x2.shape[0], meta.w1.N
+        gu = torch.empty(T, 2 * I, device=x.device, dtype=BF16)
+        _, t1 = meta.w1.forward(xn, out=gu[:, :I])
+        _, t3 = meta.w3.forward(xn, out=gu[:, I:])
+        h = K.swiglu_fwd(gu[:, :I], gu[:, I:])
+        y, t2 = meta.w2.forward(h, residual=x2 if meta.fuse_residual else None)
+        ctx.meta = meta
+        ctx.save_for_backward(x, norm_w)
+        ctx.saved = (x2, xn, rstd, gu, h, t1, t3, t2)
+        return y.view(shape)
+
+    @staticmethod
+    def backward(ctx, dy: Tensor):
+        meta: MLPBlockMeta = ctx.meta
+        x, norm_w = ctx.saved_tensors
+        x2, xn, rstd, gu, h, t1, t3, t2 = ctx.saved
+        T, I = x2.shape[0], meta.w1.N
+        dy2 = K._rows2d(dy.contiguous())
+        needs = list(ctx.needs_input_grad[3:])
+        counts = [len(p.tensors()) for p in (meta.w1, meta.w3, meta.w2)]
+        n1, n3, n2 = (needs[sum(counts[:i]) : sum(counts[: i + 1])] for i in range(3))
+        dh, g_2 = meta.w2.backward(dy2, h, t2, n2)
+        dgu = torch.empty(T, 2 * I, device=x.device, dtype=BF16)
+        K.swiglu_bwd(dh, gu[:, :I], gu[:, I:], dgu[:, :I], dgu[:, I:])
+        need_dx = ctx.needs_input_grad[0]
+        need_dxn = need_dx or (meta.fuse_norm and ctx.needs_input_grad[1])
+        dxn = torch.empty_like(x2) if need_dxn else None
+        _, g_1 = meta.w1.backward(dgu[:, :I], xn, t1, n1, need_dxn, dxn, False)
+        _, g_3 = meta.w3.backward(dgu[:, I:], xn, t3, n3, need_dxn, dxn, True)
+        dx = dnw = None
+        if meta.fuse_norm:
+            if need_dxn:
+                dx, dnw = K.rmsnorm_bwd(dxn, x2, norm_w.detach(), rstd, ctx.needs_input_grad[1])
+        else:
+            dx = dxn
+        if need_dx and meta.fuse_residual:
+            dx = K.add(dx, dy2)
+        return (dx.view(x.shape) if (dx is not None and need_dx) else None, dnw, None, *g_1, *g_3, *g_2)
+
+
+# =================================================================================================
+# final norm + LM head + cross-entropy (modelling/llama.py:216-218)
+# =================================================================================================
+class HeadLossFn(Function):
+    @staticmethod
+    def forward(ctx, x: Tensor, norm_w: Tensor, labels: Tensor, eps: float, plan: LinearPlan, *tensors):
+        K.L.require_cuda(x, labels)
+        x2 = K._rows2d(x.contiguous())
+        xn, rstd = K.rmsnorm_fwd(x2, norm_w.detach(), eps)
+        logits, t = plan.forward(xn)
+        need_grad = any(ctx.needs_input_grad)
+        loss, dlogits = K.ce_fwd_bwd(logits, labels, write_grad=need_grad)
+        ctx.plan, ctx.eps = plan, eps
+        ctx.save_for_backward(x, norm_w)
+        ctx.saved = (x2, xn, rstd, dlogits, t)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gout: Tensor):
+        plan: LinearPlan = ctx.plan
+        x, norm_w = ctx.saved_tensors
+        x2, xn, rstd, dlogits, t = ctx.saved
+        needs = ctx.needs_input_grad[5:]
+        g32 = gout.detach().to(torch.float32).reshape(1)
+        dxn, grads = plan.backward(dlogits, xn, t, needs, need_dx=ctx.needs_input_grad[0] or ctx.needs_input_grad[1])
+        grads = [None if g is None else K.scale(g, dev_scalar=g32) for g in grads]
+        dx = dnw = None
+        if dxn is not None:
+            K.scale(dxn, dev_scalar=g32, out=dxn)
+            dx, dnw = K.rmsnorm_bwd(dxn, x2, norm_w.detach(), rstd, ctx.needs_input_grad[1])
+        return (dx.view(x.shape) if dx is not None else None, dnw, None, None, None, *grads)

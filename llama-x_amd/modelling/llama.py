@@ -1,0 +1,333 @@
+"""Llama decoder with the reference's module API (/root/reference/modelling/llama.py:17-292), executing on
+hand-written gfx950 kernels.
+
+Class names, constructor signatures, parameter / state-dict names and forward signatures match the reference so
+training scripts can switch packages unchanged.  What differs is below the module boundary: every residual branch of
+a layer is ONE autograd node (llx/ops.py) that calls the HIP kernels of llama-x_amd/csrc through the C-ABI; there
+is no SDPA / FlexAttention / aten matmul on the hot path and no CPU fallback (CPU tensors raise).
+
+``block_mask`` takes a :class:`llx.kernels.MaskSpec` (per-token ``doc_ids`` / per-sample ``prefix_len``) in place of
+FlexAttention's BlockMask; the mask rule is the reference's ``mask_mod`` (train_metamathqa.py:67-68) plus the
+prefix-LM term of README.md:16.
+"""
+import json
+import os
+from typing import NamedTuple
+
+import torch
+from torch import Tensor, nn
+from torch.utils.checkpoint import checkpoint
+
+from llx import kernels as K
+from llx import ops
+from llx._lib import LlxError
+from llx.kernels import MaskSpec  # noqa: F401  (re-exported: the block_mask type of this package)
+
+
+class LlamaConfig(NamedTuple):
+    embed_dim: int
+    num_layers: int
+    head_dim: int
+    num_heads: int
+    num_kv_heads: int
+    intermediate_dim: int
+    max_seq_len: int = 2048
+    vocab_size: int = 128_256  # Llama3
+    attn_dropout: float = 0.0
+    rope_base: int = 50_000
+    is_llama3_1: bool = False
+    activation_checkpointing: bool = False
+
+
+# ------------------------------------------------------------------------------------------------- RoPE
+def scale_llama3_1_rope(freqs: Tensor) -> Tensor:
+    """Llama-3.1 frequency rescale (factor 8, low 1, high 4, original context 8192), host side, fp32."""
+    factor, low, high, ctx_len = 8, 1, 4, 8192
+    wavelen = 2 * torch.pi / freqs
+    ratio = (ctx_len / wavelen - low) / (high - low)
+    blended = (1 - ratio) * freqs / factor + ratio * freqs
+    long_wave = torch.where(wavelen > ctx_len / low, freqs / factor, blended)
+    return torch.where(wavelen < ctx_len / high, freqs, long_wave).to(freqs.dtype)
+
+
+def build_rope(config: LlamaConfig) -> Tensor:
+    """fp32 [max_seq_len, head_dim/2, 2] table of (cos, sin); built on the host for bit parity of the table."""
+    half = torch.arange(0, config.head_dim, 2, dtype=torch.float32) / config.head_dim
+    theta = 1.0 / (config.rope_base**half)
+    if config.is_llama3_1:
+        theta = scale_llama3_1_rope(theta)
+    angle = torch.outer(torch.arange(config.max_seq_len, dtype=torch.float32), theta)
+    return torch.stack([angle.cos(), angle.sin()], dim=-1)
+
+
+class _RopeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x: Tensor, table: Tensor):
+        B, S, H, hd = x.shape
+        ctx.table, ctx.shape = table, x.shape
+        y = x.contiguous().clone().view(B, S, H * hd)
+        return K.rope_(y, table, H).view(B, S, H, hd)
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        B, S, H, hd = ctx.shape
+        y = g.contiguous().clone().view(B, S, H * hd)
+        return K.rope_(y, ctx.table, H, backward=True).view(B, S, H, hd), None
+
+
+def _rope_f32(rope: Tensor) -> Tensor:
+    # model.bfloat16() also casts the buffer (train_metamathqa.py:176): keep those rounded values, widen for the kernel
+    return rope if rope.dtype is torch.float32 else ops._cached(rope, "f32", lambda: rope.float())
+
+
+def apply_rope(x: Tensor, rope: Tensor) -> Tensor:
+    """Interleaved-pair rotation of x [B, S, H, 128] by the first S rows of ``rope`` (fp32 math, one rounding)."""
+    return _RopeFn.apply(x, _rope_f32(rope).contiguous())
+
+
+# ------------------------------------------------------------------------------------------------- leaf modules
+class Linear(nn.Linear):
+    """nn.Linear whose stand-alone forward runs the llx GEMM (still an nn.Linear for quantize_/adapter surgery)."""
+
+    def forward(self, x: Tensor) -> Tensor:
+        return ops.linear(x, self)
+
+
+class RMSNorm(nn.RMSNorm):
+    def forward(self, x: Tensor) -> Tensor:
+        return ops.rmsnorm(x, self.weight, self.eps)
+
+
+class _EmbeddingFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ids: Tensor, table: Tensor):
+        ctx.save_for_backward(ids)
+        ctx.vocab = table.shape[0]
+        return K.embedding_fwd(ids, table.detach())
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        (ids,) = ctx.saved_tensors
+        return None, K.embedding_bwd(ids, g.contiguous(), ctx.vocab).to(g.dtype)
+
+
+class Embedding(nn.Embedding):
+    def forward(self, ids: Tensor) -> Tensor:
+        return _EmbeddingFn.apply(ids, self.weight)
+
+
+class KVCache(nn.Module):
+    def __init__(self, batch_size: int, config: LlamaConfig, dtype: torch.dtype):
+        super().__init__()
+        shape = (batch_size, config.num_kv_heads, config.max_seq_len, config.head_dim)
+        self.register_buffer("k_cache", torch.zeros(shape, dtype=dtype), persistent=False)
+        self.register_buffer("v_cache", torch.zeros(shape, dtype=dtype), persistent=False)
+
+    def update(self, input_pos: Tensor, k: Tensor, v: Tensor):
+        # input_pos: [S], k/v: [B, KVH, S, hd]
+        assert input_pos.shape[0] == k.shape[2], (input_pos.shape, k.shape)
+        self.k_cache[:, :, input_pos] = k
+        self.v_cache[:, :, input_pos] = v
+        return self.k_cache, self.v_cache
+
+
+def _as_maskspec(block_mask):
+    if block_mask is None or isinstance(block_mask, MaskSpec):
+        return block_mask
+    raise LlxError(
+        "block_mask must be an llx MaskSpec(doc_ids=..., prefix_len=...) - FlexAttention BlockMask objects are not "
+        "dispatched on this platform (the mask rule is evaluated on device from per-token metadata)"
+    )
+
+
+# ------------------------------------------------------------------------------------------------- blocks
+class Attention(nn.Module):
+    def __init__(self, config: LlamaConfig) -> None:
+        super().__init__()
+        self.num_heads = config.num_heads
+        self.num_kv_heads = config.num_kv_heads
+        self.embed_dim = config.embed_dim
+        self.attn_dropout = config.attn_dropout
+        self.head_dim = config.head_dim
+
+        self.wq = Linear(self.embed_dim, self.num_heads * self.head_dim, bias=False)
+        self.wk = Linear(self.embed_dim, self.num_kv_heads * self.head_dim, bias=False)
+        self.wv = Linear(self.embed_dim, self.num_kv_heads * self.head_dim, bias=False)
+        self.wo = Linear(self.num_heads * self.head_dim, self.embed_dim, bias=False)
+        self.kv_cache = None
+
+    def _run(self, x: Tensor, rope: Tensor, norm: nn.Module | None, residual: bool, mask, input_pos, block_mask) -> Tensor:
+        if self.kv_cache is not None or mask is not None or input_pos is not None:
+            raise LlxError("KV-cache / dense-mask inference attention is not built yet on this platform (training path only)")
+        if self.training and self.attn_dropout > 0.0:
+            raise LlxError("attention dropout is not supported by the HIP attention kernel (reference default is 0.0)")
+        plans = [ops.LinearPlan(m) for m in (self.wq, self.wk, self.wv, self.wo)]
+        meta = ops.AttnBlockMeta(plans, self.num_heads, self.num_kv_heads, self.head_dim, _as_maskspec(block_mask),
+                                 norm.eps if norm is not None else 0.0, norm is not None, residual)
+        tensors = [t for p in plans for t in p.tensors()]
+        return ops.AttnBlockFn.apply(x, _rope_f32(rope), norm.weight if norm is not None else None, meta, *tensors)
+
+    def forward(self, x: Tensor, rope: Tensor, *, mask: Tensor | None = None, input_pos: Tensor | None = None,
+                block_mask=None) -> Tensor:
+        return self._run(x, rope, None, False, mask, input_pos, block_mask)
+
+
+class FeedForward(nn.Module):
+    def __init__(self, config: LlamaConfig):
+        super().__init__()
+        self.w1 = Linear(config.embed_dim, config.intermediate_dim, bias=False)
+        self.w3 = Linear(config.embed_dim, config.intermediate_dim, bias=False)
+        self.w2 = Linear(config.intermediate_dim, config.embed_dim, bias=False)
+        self.act = nn.SiLU()
+
+    def _run(self, x: Tensor, norm: nn.Module | None, residual: bool) -> Tensor:
+        plans = [ops.LinearPlan(m) for m in (self.w1, self.w3, self.w2)]
+        meta = ops.MLPBlockMeta(plans, norm.eps if norm is not None else 0.0, norm is not None, residual)
+        tensors = [t for p in plans for t in p.tensors()]
+        return ops.MLPBlockFn.apply(x, norm.weight if norm is not None else None, meta, *tensors)
+
+    def forward(self, x: Tensor) -> Tensor:
+        return self._run(x, None, False)
+
+
+class TransformerLayer(nn.Module):
+    def __init__(self, config: LlamaConfig) -> None:
+        super().__init__()
+        self.attention_norm = RMSNorm(config.embed_dim, eps=1e-5)
+        self.attention = Attention(config)
+        self.ffn_norm = RMSNorm(config.embed_dim, eps=1e-5)
+        self.feed_forward = FeedForward(config)
+
+    def forward(self, x: Tensor, rope: Tensor, *, mask: Tensor | None = None, input_pos: Tensor | None = None,
+                block_mask=None) -> Tensor:
+        # x + attention(attention_norm(x)) and x + feed_forward(ffn_norm(x)), each as one fused autograd node
+        x = self.attention._run(x, rope, self.attention_norm, True, mask, input_pos, block_mask)
+        return self.feed_forward._run(x, self.ffn_norm, True)
+
+
+class Llama(nn.Module):
+    def __init__(self, config: LlamaConfig) -> None:
+        super().__init__()
+        self.tok_embeddings = Embedding(config.vocab_size, config.embed_dim)
+        self.layers = nn.ModuleList([TransformerLayer(config) for _ in range(config.num_layers)])
+        self.norm = RMSNorm(config.embed_dim, eps=1e-5)
+        self.output = Linear(config.embed_dim, config.vocab_size, bias=False)
+        self.config = config
+
+    def build_cache(self, inference: bool = False):
+        self.register_buffer("rope", build_rope(self.config), persistent=False)
+        if inference:
+            for layer in self.layers:
+                layer.attention.kv_cache = KVCache(1, self.config, self.tok_embeddings.weight.dtype)
+            L = self.config.max_seq_len
+            self.register_buffer("causal_mask", torch.tril(torch.ones(L, L, dtype=torch.bool)), persistent=False)
+
+    def _run_layers(self, x: Tensor, rope: Tensor, **kw) -> Tensor:
+        for layer in self.layers:
+            if self.config.activation_checkpointing:
+                x = checkpoint(layer, x, rope, use_reentrant=False, **kw)
+            else:
+                x = layer(x, rope, **kw)
+        return x
+
+    def _head(self, x: Tensor, labels: Tensor | None) -> Tensor:
+        if labels is None:
+            return self.output(self.norm(x))
+        plan = ops.LinearPlan(self.output)
+        return ops.HeadLossFn.apply(x, self.norm.weight, labels, self.norm.eps, plan, *plan.tensors())
+
+    def forward(self, x: Tensor, *, input_pos: Tensor | None = None, block_mask=None, labels: Tensor | None = None) -> Tensor:
+        mask = self.causal_mask[None, None, input_pos] if input_pos is not None else None  # inference path (generate)
+        x = self.tok_embeddings(x)
+        rope = self.rope[: x.shape[1]]
+        x = self._run_layers(x, rope, mask=mask, input_pos=input_pos, block_mask=block_mask)
+        return self._head(x, labels)
+
+    @staticmethod
+    def from_hf(model_id: str, **kwargs):
+        config = _get_hf_config(model_id)._replace(**kwargs)
+        with torch.device("meta"):
+            model = Llama(config).eval()
+        # the cache cannot be built under the meta device: load (assign) first, then build
+        model.load_state_dict(_get_hf_state_dict(model_id), assign=True)
+        model.build_cache()
+        return model
+
+
+# ------------------------------------------------------------------------------------------------- HF loading
+def _hf_file(model_id: str, filename: str) -> str:
+    """A local checkpoint directory is used as is; otherwise the hub is asked (needs network, as in the reference)."""
+    if os.path.isdir(model_id):
+        return os.path.join(model_id, filename)
+    from huggingface_hub import hf_hub_download
+
+    return hf_hub_download(model_id, filename)
+
+
+def _hf_list(model_id: str) -> list[str]:
+    if os.path.isdir(model_id):
+        return sorted(os.listdir(model_id))
+    from huggingface_hub import list_repo_files
+
+    return list_repo_files(model_id)
+
+
+def _get_hf_config(model_id: str) -> LlamaConfig:
+    with open(_hf_file(model_id, "config.json")) as f:
+        hf = json.load(f)
+    assert hf["architectures"][0] == "LlamaForCausalLM"
+    config = LlamaConfig(
+        embed_dim=hf["hidden_size"],
+        num_layers=hf["num_hidden_layers"],
+        head_dim=hf.get("head_dim", hf["hidden_size"] // hf["num_attention_heads"]),
+        num_heads=hf["num_attention_heads"],
+        num_kv_heads=hf["num_key_value_heads"],
+        intermediate_dim=hf["intermediate_size"],
+        vocab_size=hf["vocab_size"],
+    )
+    if "rope_theta" in hf:
+        config = config._replace(rope_base=hf["rope_theta"])
+    if hf.get("rope_scaling", None) is not None:
+        config = config._replace(is_llama3_1=hf["rope_scaling"]["rope_type"] == "llama3")
+    return config
+
+
+_HF_RENAMES = (
+    ("embed_tokens", "tok_embeddings"),
+    ("self_attn.q_proj", "attention.wq"),
+    ("self_attn.k_proj", "attention.wk"),
+    ("self_attn.v_proj", "attention.wv"),
+    ("self_attn.o_proj", "attention.wo"),
+    ("mlp.gate_proj", "feed_forward.w1"),
+    ("mlp.up_proj", "feed_forward.w3"),
+    ("mlp.down_proj", "feed_forward.w2"),
+    ("input_layernorm", "attention_norm"),
+    ("post_attention_layernorm", "ffn_norm"),
+    ("lm_head", "output"),
+)
+
+
+def _rename_hf_key(key: str) -> str:
+    key = key.removeprefix("model.")
+    for old, new in _HF_RENAMES:
+        key = key.replace(old, new)
+    return key
+
+
+def _get_hf_state_dict(model_id: str) -> dict:
+    names = _hf_list(model_id)
+    filenames = [n for n in names if n.endswith(".safetensors")] or [n for n in names if n.endswith(".bin")]
+    if not filenames:
+        raise RuntimeError(f"No weights found for {model_id=}")
+    state = {}
+    for name in filenames:
+        path = _hf_file(model_id, name)
+        if path.endswith(".safetensors"):
+            import safetensors
+
+            with safetensors.safe_open(path, framework="pt") as f:
+                for k in f.keys():
+                    state[k] = f.get_tensor(k)
+        else:
+            state.update(torch.load(path, map_location="cpu", weights_only=True, mmap=True))
+    return {_rename_hf_key(k): v for k, v in state.items()}

@@ -1,0 +1,52 @@
+"""``torchao::int8_mm_dequant(Tensor A, Tensor B, Tensor A_scale, Tensor B_scale) -> Tensor`` on gfx950.
+
+Same schema, assertions and Meta behaviour as the reference's Triton op (/root/reference/subclasses/int8_mm.py:121-149);
+the device implementation is the i8-MFMA GEMM of llama-x_amd/csrc/gemm_bf16.hip (v_mfma_i32_16x16x64_i8, int32
+accumulate, fp32 row*col scale epilogue, one rounding to the scale dtype).  As in the reference there is no CPU kernel.
+"""
+import torch
+from torch import Tensor
+
+from llx import _lib as L
+
+_lib = torch.library.Library("torchao", "FRAGMENT")
+_lib.define("int8_mm_dequant(Tensor A, Tensor B, Tensor A_scale, Tensor B_scale) -> Tensor")
+
+
+def int8_mm_dequant(A: Tensor, B: Tensor, A_scale_rowwise: Tensor, B_scale_colwise: Tensor) -> Tensor:
+    assert A.dtype is torch.int8 and B.dtype is torch.int8
+    assert A_scale_rowwise.dtype is B_scale_colwise.dtype
+    assert A.shape[1] == B.shape[0]
+    assert A_scale_rowwise.squeeze().shape == (A.shape[0],)
+    assert B_scale_colwise.squeeze().shape == (B.shape[1],)
+    assert A_scale_rowwise.is_contiguous()
+    assert B_scale_colwise.is_contiguous()
+    return torch.ops.torchao.int8_mm_dequant(A, B, A_scale_rowwise, B_scale_colwise)
+
+
+@torch.library.impl(_lib, "int8_mm_dequant", "Meta")
+def _meta(A, B, A_scale_rowwise, B_scale_colwise):
+    return torch.empty((A.shape[0], B.shape[1]), device=A.device, dtype=A_scale_rowwise.dtype)
+
+
+def _launch(A: Tensor, Bt: Tensor, a_scale: Tensor, b_scale: Tensor, out: Tensor | None = None) -> Tensor:
+    """A [M,K] int8 rows, Bt [N,K] int8 rows (= B^T), scales bf16 -> out [M,N] bf16."""
+    M, Kd = A.shape
+    N = Bt.shape[0]
+    if a_scale.dtype is not torch.bfloat16:
+        raise L.LlxError(f"int8_mm_dequant: scales must be bf16 on the HIP path (got {a_scale.dtype})")
+    if out is None:
+        out = torch.empty(M, N, device=A.device, dtype=torch.bfloat16)
+    L.check(L.load().llx_int8_mm_dequant(L.ptr(A), A.stride(0), L.ptr(Bt), Bt.stride(0), L.ptr(out), out.stride(0), M, N, Kd,
+                                         L.ptr(a_scale), L.ptr(b_scale), L.stream()), "llx_int8_mm_dequant")
+    return out
+
+
+@torch.library.impl(_lib, "int8_mm_dequant", "CUDA")  # "CUDA" is the HIP dispatch key on PyTorch-ROCm
+def _hip(A, B, A_scale_rowwise, B_scale_colwise):
+    A = A if A.stride(1) == 1 else A.contiguous()
+    # the kernel wants B's columns K-contiguous: B = W.T with strides (1, K) (reference call site subclasses/int8.py:113)
+    Bt = B.t()
+    if Bt.stride(1) != 1:
+        Bt = Bt.contiguous()
+    return _launch(A, Bt, A_scale_rowwise.reshape(-1), B_scale_colwise.reshape(-1))

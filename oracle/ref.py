@@ -324,19 +324,33 @@ def int8_mm_dequant(a_i8: Tensor, b_i8: Tensor, a_scale: Tensor, b_scale: Tensor
     return out.to(a_scale.dtype)
 
 
-def int8_linear(x: Tensor, w_i8: Tensor, w_scale: Tensor, dynamic: bool = False, bias: Optional[Tensor] = None) -> Tensor:
-    """_Int8Linear.forward (subclasses/int8.py:106-121)."""
-    if dynamic:
-        xi, xs = quantize_int8_rowwise(x.reshape(-1, w_i8.shape[1]))
-        out = int8_mm_dequant(xi, w_i8.T, xs, w_scale).view(*x.shape[:-1], -1)
-    else:
-        out = (x @ w_i8.T.to(x.dtype)) * w_scale
-    return out + bias if bias is not None else out
-
-
 def int8_linear_grad_input(grad_out: Tensor, w_i8: Tensor, w_scale: Tensor) -> Tensor:
     """_Int8Linear.backward (subclasses/int8.py:124-127): (g * scale) @ W_i8.to(g.dtype)."""
     return (grad_out * w_scale) @ w_i8.to(grad_out.dtype)
+
+
+class _Int8LinearRef(torch.autograd.Function):
+    """_Int8Linear (subclasses/int8.py:106-130): the forward may quantise the activations (non-differentiable rounding),
+    the backward is always the bf16/fp32 dequantised product - so it has to be an explicit autograd function."""
+
+    @staticmethod
+    def forward(ctx, x, w_i8, w_scale, dynamic):
+        ctx.save_for_backward(w_i8, w_scale)
+        if dynamic:
+            xi, xs = quantize_int8_rowwise(x.reshape(-1, w_i8.shape[1]))
+            return int8_mm_dequant(xi, w_i8.T, xs, w_scale.to(xs.dtype)).view(*x.shape[:-1], -1)
+        return (x @ w_i8.T.to(x.dtype)) * w_scale
+
+    @staticmethod
+    def backward(ctx, g):
+        w_i8, w_scale = ctx.saved_tensors
+        return int8_linear_grad_input(g, w_i8, w_scale), None, None, None
+
+
+def int8_linear(x: Tensor, w_i8: Tensor, w_scale: Tensor, dynamic: bool = False, bias: Optional[Tensor] = None) -> Tensor:
+    """F.linear on an Int8LinearWeight (subclasses/int8.py:60-64,106-121)."""
+    out = _Int8LinearRef.apply(x, w_i8, w_scale, dynamic)
+    return out + bias if bias is not None else out
 
 
 def int8_dequantize(w_i8: Tensor, w_scale: Tensor) -> Tensor:
