@@ -1,0 +1,219 @@
+"""Headline benchmark: train tokens/sec of Llama-3.1-8B, LoRA r=16, bf16, seq 4096, on N MI355X (BASELINE.json).
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One "step" = forward + backward + (gradient all-reduce) + AdamW step over one synthetic 4096-token batch per GPU
+(config C2 of SURVEY 8d: text only, causal, base + LM head + embeddings frozen, LoRA on model.layers, norm weights
+trainable).  Weights are random-init at Llama-3.1-8B dimensions (no checkpoints offline).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "llama-x_amd"))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+# algorithmic FLOPs per token of the LoRA training step at S=4096: fwd + dgrad through every base linear
+# and the frozen LM head, causal attention at half, recompute not counted
+GF_PER_TOKEN = {4096: 34.0, 8192: 37.8}
+BF16_DENSE_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
+
+
+def build_model(cfg_name: str, seq: int, rank: int, device):
+    from modelling import Llama, LlamaConfig, apply_linear_adapter_
+
+    if cfg_name == "llama31_8b":
+        cfg = LlamaConfig(embed_dim=4096, num_layers=32, head_dim=128, num_heads=32, num_kv_heads=8, intermediate_dim=14336,
+                          max_seq_len=seq, vocab_size=128_256, rope_base=500_000, is_llama3_1=True)
+    else:  # small config for plumbing checks
+        cfg = LlamaConfig(embed_dim=512, num_layers=2, head_dim=128, num_heads=4, num_kv_heads=1, intermediate_dim=1792,
+                          max_seq_len=seq, vocab_size=1024, rope_base=500_000, is_llama3_1=True)
+    with torch.device("meta"):
+        model = Llama(cfg)
+    model = model.to(torch.bfloat16).to_empty(device=device)
+    g = torch.Generator(device=device)
+    g.manual_seed(1234)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if name.endswith("norm.weight"):
+                p.fill_(1.0)
+            else:
+                p.normal_(0.0, 0.02, generator=g)
+    model.build_cache()
+    model.rope = model.rope.to(device)
+    for n, p in model.named_parameters():
+        p.requires_grad_(False)
+    apply_linear_adapter_(model.layers, "lora", rank=rank, alpha=float(rank))
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.endswith("lora_b"):
+                p.normal_(0.0, 0.01, generator=g)  # non-zero so that every gradient path carries signal
+    for n, p in model.named_parameters():
+        if n.startswith("layers.") and n.endswith("_norm.weight"):
+            p.requires_grad_(True)  # layer norms stay trainable as in the reference scripts
+    return model.train(), cfg
+
+
+def cpu_baseline(seq: int, rank: int):
+    """Oracle (CPU restatement of the reference) timed on the host cores on a bounded sample of the same workload."""
+    from oracle import ref as O
+
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 64))  # a 1-GPU box shares its host: use the cores this process may run on
+    torch.set_num_threads(cores)
+    S = min(seq, 1024)
+    cfg = O.LLAMA31_8B._replace(num_layers=1, max_seq_len=S)
+    D, I = cfg.embed_dim, cfg.intermediate_dim
+    p = {}
+    hq, hkv = cfg.num_heads * cfg.head_dim, cfg.num_kv_heads * cfg.head_dim
+    shapes = {"attention.wq": (hq, D), "attention.wk": (hkv, D), "attention.wv": (hkv, D), "attention.wo": (D, hq),
+              "feed_forward.w1": (I, D), "feed_forward.w3": (I, D), "feed_forward.w2": (D, I)}
+    gen = torch.Generator().manual_seed(0)
+    for suf, (o, n) in shapes.items():
+        p[f"layers.0.{suf}.weight"] = torch.randn(o, n, generator=gen) * 0.02
+        p[f"layers.0.{suf}.lora_a"] = (torch.randn(rank, n, generator=gen) * 0.01).requires_grad_()
+        p[f"layers.0.{suf}.lora_b"] = (torch.randn(o, rank, generator=gen) * 0.01).requires_grad_()
+    p["layers.0.attention_norm.weight"] = torch.ones(D, requires_grad=True)
+    p["layers.0.ffn_norm.weight"] = torch.ones(D, requires_grad=True)
+    x = (torch.randn(1, S, D, generator=gen) * 0.5).requires_grad_()
+    table = O.rope_table(cfg)
+    t0 = time.perf_counter()
+    y = O.layer(x, p, 0, cfg, table, None, 1.0)
+    y.sum().backward()
+    t_layer = time.perf_counter() - t0
+    # LM head + CE on a slice of positions
+    Sh = 256
+    w_out = torch.randn(128_256, D, generator=gen) * 0.02
+    h = (torch.randn(1, Sh, D, generator=gen) * 0.5).requires_grad_()
+    labels = torch.randint(0, 128_256, (1, Sh), generator=gen)
+    t0 = time.perf_counter()
+    loss = O.cross_entropy(torch.nn.functional.linear(O.rmsnorm(h, torch.ones(D)), w_out), labels)
+    loss.backward()
+    t_head = time.perf_counter() - t0
+    step_s = 32 * t_layer * (seq / S) + t_head * (seq / Sh)  # linear extrapolation in tokens (under-counts attention's S^2 term)
+    return {"value": round(seq / step_s, 3), "unit": "tokens/s", "cores": cores, "kind": "port",
+            "sample": f"oracle fp32: 1 of 32 layers (8B dims, LoRA r={rank}) fwd+bwd at S={S} took {t_layer:.2f}s, LM head+CE on {Sh} positions "
+                      f"{t_head:.2f}s; extrapolated linearly to 32 layers and S={seq}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--seq", type=int, default=4096)
+    ap.add_argument("--rank", type=int, default=16)
+    ap.add_argument("--model", default="llama31_8b", choices=["llama31_8b", "tiny"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)  # "nccl" is RCCL on ROCm
+
+    from llx import kernels as K
+    from llx.dp import GradBuckets
+
+    model, cfg = build_model(args.model, args.seq, args.rank, device)
+    trainable = [p for p in model.parameters() if p.requires_grad]
+    buckets = GradBuckets(model, n_buckets=4)
+    optim = torch.optim.AdamW(trainable, lr=1e-4, weight_decay=0.0, fused=True)
+
+    S = args.seq
+    gen = torch.Generator(device=device)
+    gen.manual_seed(rank)  # rank-distinct data streams
+    def batch():
+        ids = torch.randint(0, cfg.vocab_size, (1, S), device=device, generator=gen)
+        labels = torch.roll(ids, -1, 1)
+        labels[:, : S // 4] = -100
+        labels[:, -1] = -100
+        return ids, labels
+
+    def step():
+        ids, labels = batch()
+        loss = model(ids, labels=labels)
+        loss.backward()
+        buckets.finish()
+        optim.step()
+        buckets.zero_grad()
+        return loss
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+
+    # ---- live roofline of the dominant kernel (the bf16 MFMA GEMM): one more step with HIP events around every launch
+    gemm_stats = None
+    if rank == 0:
+        K.GEMM_TRACE = []
+        step()
+        torch.cuda.synchronize()
+        tr = K.GEMM_TRACE
+        K.GEMM_TRACE = None
+        tot_ms = sum(s.elapsed_time(e) for s, e, _ in tr)
+        tot_fl = sum(f for _, _, f in tr)
+        gemm_stats = {"launches": len(tr), "ms": tot_ms, "flops": tot_fl}
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        tokens = S * world * args.steps
+        value = tokens / elapsed
+        out = {
+            "metric": "train tokens/sec Llama-3.1-8B seq4096 at 1/2/4/8 MI355X; p50 step ms",
+            "value": round(value, 1), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"Llama-3.1-8B text-only LoRA r={args.rank} bf16, seq={S}, 1 sequence per GPU, causal mask, base+LM head frozen "
+                                   "(BASELINE.json configs[1]); random-init weights at 8B dimensions" if args.model == "llama31_8b" else f"tiny plumbing config seq={S}",
+                       "global_batch_tokens": S * world, "seq_len": S, "parallelism": f"dp{world}", "loss": round(float(loss.detach()), 4)},
+        }
+        gf = GF_PER_TOKEN.get(S)
+        if gf and args.model == "llama31_8b":
+            out["step_mfma_frac"] = round(gf * 1e9 * S / (ms_per_step * 1e-3) / 1e12 / BF16_DENSE_PEAK_TFLOPS, 4)
+        if gemm_stats and gemm_stats["ms"] > 0:
+            ach = gemm_stats["flops"] / (gemm_stats["ms"] * 1e-3) / 1e12
+            out["roofline"] = {"bound": "mfma", "achieved": round(ach, 1), "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": round(ach / BF16_DENSE_PEAK_TFLOPS, 4), "traffic": None, "kernel": "gemm_nt_kernel (bf16 MFMA GEMM)",
+                               "launches_per_step": gemm_stats["launches"], "avg_launch_us": round(gemm_stats["ms"] * 1e3 / max(1, gemm_stats["launches"]), 2),
+                               "gemm_ms_per_step": round(gemm_stats["ms"], 2)}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(S, args.rank)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

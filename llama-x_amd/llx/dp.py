@@ -1,0 +1,78 @@
+"""Data-parallel gradient exchange: one process per GPU, RCCL all-reduce over xGMI, overlapped with backward.
+
+The reference has no distributed code; the single exchange of a data-parallel step is the mean of the
+TRAINABLE gradients (LoRA factors + norm weights: ~84 MB bf16 for Llama-3.1-8B r=16).  Gradients live in flat
+contiguous bucket buffers (each ``param.grad`` is a view), buckets are filled in reverse layer order by backward and
+each bucket's all-reduce is launched from a post-accumulate-grad hook as soon as its last gradient has landed, on
+RCCL's own stream; ``finish()`` makes the optimizer stream wait.  xGMI is point-to-point: with payloads this small the
+cost is latency, so few large buckets beat many small ones (default 4 buckets).
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+from torch import nn
+
+
+class GradBuckets:
+    def __init__(self, model: nn.Module, n_buckets: int = 4, process_group=None):
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        params = [p for p in model.parameters() if p.requires_grad]
+        # backward produces gradients roughly in reverse registration order: bucket 0 = last layers
+        params = list(reversed(params))
+        total = sum(p.numel() for p in params)
+        target = (total + n_buckets - 1) // max(1, n_buckets)
+        self.buckets: list[dict] = []
+        cur, cur_n = [], 0
+        for p in params:
+            cur.append(p)
+            cur_n += p.numel()
+            if cur_n >= target:
+                self.buckets.append(self._make(cur))
+                cur, cur_n = [], 0
+        if cur:
+            self.buckets.append(self._make(cur))
+        self._handles = []
+        self._hooks = []
+        if self.world > 1:
+            for bi, b in enumerate(self.buckets):
+                for p in b["params"]:
+                    self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(bi)))
+        self.sync_enabled = True  # set False on non-final micro-batches of gradient accumulation
+
+    def _make(self, params):
+        dtype, device = params[0].dtype, params[0].device
+        assert all(p.dtype == dtype for p in params), "a bucket holds one dtype"
+        flat = torch.zeros(sum(p.numel() for p in params), dtype=dtype, device=device)
+        off = 0
+        for p in params:
+            p.grad = flat[off : off + p.numel()].view_as(p)
+            off += p.numel()
+        return {"params": params, "flat": flat, "pending": len(params)}
+
+    def _make_hook(self, bi: int):
+        def hook(param):
+            b = self.buckets[bi]
+            b["pending"] -= 1
+            if b["pending"] == 0 and self.sync_enabled:
+                self._launch(b)
+
+        return hook
+
+    def _launch(self, b):
+        b["flat"].div_(self.world)  # pre-scale: sum of means = mean of sums, keeps bf16 range
+        self._handles.append(dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+
+    def finish(self):
+        """Call after backward, before clip / optimizer.step: waits for the in-flight bucket all-reduces."""
+        for h in self._handles:
+            h.wait()
+        self._handles.clear()
+        for b in self.buckets:
+            b["pending"] = len(b["params"])
+
+    def zero_grad(self):
+        """Keep the views, zero the storage (optimizer.zero_grad(set_to_none=True) would drop the views)."""
+        for b in self.buckets:
+            b["flat"].zero_()

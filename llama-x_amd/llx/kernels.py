@@ -16,6 +16,7 @@ from . import _lib as L
 BF16 = torch.bfloat16
 EPI_NONE, EPI_RESIDUAL, EPI_BIAS, EPI_BIAS_GELU, EPI_COLSCALE = 0, 1, 2, 3, 4
 SK_PAD = 64
+GEMM_TRACE = None  # bench.py sets this to a list to collect (start_event, end_event, algorithmic_flops) per GEMM launch
 
 
 def _lib():
@@ -89,9 +90,16 @@ def gemm_nt(a: Tensor, b: Tensor, *, out: Optional[Tensor] = None, a2: Optional[
         lde = e.stride(0)
     elif epilogue != EPI_NONE:
         assert e is not None and e.shape == (N,) and e.is_contiguous()
+    ev = None
+    if GEMM_TRACE is not None:
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
     L.check(_lib().llx_gemm_nt_bf16(L.ptr(a), a.stride(0), L.ptr(b), b.stride(0), L.ptr(out), out.stride(0), M, N, K,
                                     L.ptr(a2), a2.stride(0) if a2 is not None else 0, L.ptr(b2), b2.stride(0) if b2 is not None else 0, K2,
                                     epilogue, L.ptr(e), lde, L.stream()), "llx_gemm_nt_bf16")
+    if ev is not None:
+        ev[1].record()
+        GEMM_TRACE.append((ev[0], ev[1], 2.0 * M * N * (K + K2)))
     return out
 
 
