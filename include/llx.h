@@ -1,0 +1,116 @@
+/* llx.h - C ABI of libllx_hip.so: the MI355X (gfx950) kernels behind the llama-x training hot path.
+ *
+ * Drop-in boundary: the reference (gau-nernst/llama-x) is pure Python and reaches the
+ * device through PyTorch / Triton calls inside its `modelling` and `subclasses` packages.  This library is what the
+ * Python side of those packages binds (ctypes) instead; each entry point names the reference call site it replaces
+ * (paths relative to the reference root).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless stated otherwise;
+ *   - bf16 tensors are passed as `const void*` to raw 16-bit storage, row-major, last dimension contiguous;
+ *     `ld*` / `*_ss` / `*_sb` are strides in ELEMENTS;
+ *   - the caller owns every buffer (PyTorch's caching allocator); the library never allocates, frees, retains or
+ *     synchronises; workspaces are caller-provided (size queries are host functions);
+ *   - every launcher takes the stream to launch on (`hipStream_t`, passed as void* from ctypes) and is re-entrant;
+ *   - return value 0 = success; negative = error (-1 bad argument, -2 launch failure, -3 unsupported); the message is
+ *     in llx_last_error_string() (thread-local).  No exceptions, no abort.
+ */
+#ifndef LLX_H
+#define LLX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* llx_stream_t; /* hipStream_t */
+
+/* ---- library ------------------------------------------------------------------------------------------------ */
+int llx_version(void);                                   /* 100 = 0.1.0 */
+const char* llx_last_error_string(void);                 /* thread-local, valid until the next failing call */
+int llx_device_info(int device, char* name, int len);    /* returns CU count, fills gcn arch name */
+
+/* ---- RMSNorm: nn.RMSNorm(D, eps=1e-5) at modelling/llama.py:158,160,182 (called :172,173,216) ----------------- */
+int llx_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int64_t rows, int64_t dim, float eps, llx_stream_t s);
+int64_t llx_rmsnorm_bwd_workspace_bytes(int64_t rows, int64_t dim);
+int llx_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rstd, void* dx, void* dw /*nullable*/,
+                    int dw_accumulate, void* workspace, int64_t rows, int64_t dim, llx_stream_t s);
+
+/* ---- bf16 MFMA GEMM, C[M,N] = A[M,K].B[N,K]^T (+ A2[M,K2].B2[N,K2]^T): every F.linear of the layer
+ *      (modelling/llama.py:118-120,140,152,216), its data gradients (on a transposed weight image), the LoRA adapter
+ *      as K-extension (modelling/lora.py:43) and the audio convolutions as implicit GEMMs (modelling/audio.py:26-31).
+ *      epilogue: 0 none | 1 + E[M,N] (ld = lde) | 2 + bias E[N] | 3 gelu(+bias E[N]) | 4 * colscale E[N]
+ *      (weight-only int8, subclasses/int8.py:118).  K, K2 multiples of 64; N multiple of 8. ------------------------ */
+int llx_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
+                     const void* A2, int64_t lda2, const void* B2, int64_t ldb2, int64_t K2, int epilogue, const void* E, int64_t lde,
+                     llx_stream_t s);
+
+/* ---- torchao::int8_mm_dequant(A, B, A_scale, B_scale) - subclasses/int8_mm.py:121-149 (Triton kernel :50-118).
+ *      A int8 [M,K]; B passed as its K-contiguous rows [N,K] (= the reference's int_data.T view, strides (1,K));
+ *      scales bf16; C bf16 = (int32 acc) * a_scale[m] * b_scale[n], one rounding.  K multiple of 128. ----------- */
+int llx_int8_mm_dequant(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
+                        const void* a_scale, const void* b_scale, llx_stream_t s);
+
+/* ---- quantize_int8_rowwise - subclasses/int8.py:10-16 (weights once, activations per forward when dynamic). ---- */
+int llx_quantize_int8_rowwise(const void* x, int64_t ldx, void* q, int64_t ldq, void* scale, int64_t rows, int64_t cols, int is_f32,
+                              llx_stream_t s);
+
+/* ---- attention: F.scaled_dot_product_attention(..., enable_gqa=True) and flex_attention(block_mask=...) at
+ *      modelling/llama.py:129-137; mask rule = mask_mod of train_metamathqa.py:67-68 plus the prefix-LM term
+ *      (README.md:16): allow(q,k) = (k <= q || k < prefix_len[b]) && (!doc_ids || doc_ids[b,q] == doc_ids[b,k]).
+ *      q [B,S,H,128], k/v [B,S,KVH,128] with free batch/sequence strides; lse fp32 [B,H,S] (log2 units).
+ *      flags: tile classes built by llx_attn_tile_flags (needed only with doc_ids / prefix_len). ----------------- */
+int64_t llx_attn_flags_bytes(int64_t B, int64_t S);
+int llx_attn_tile_flags(const int* doc_ids, const int* prefix_len, void* flags, int64_t B, int64_t S, llx_stream_t s);
+int llx_attn_fwd(const void* q, int64_t q_sb, int64_t q_ss, const void* k, int64_t k_sb, int64_t k_ss, const void* v, int64_t v_sb,
+                 int64_t v_ss, void* o, int64_t o_sb, int64_t o_ss, float* lse, const int* doc_ids, const int* prefix_len,
+                 const void* flags, int64_t B, int64_t S, int64_t H, int64_t KVH, int64_t head_dim, float scale, llx_stream_t s);
+int llx_attn_bwd(const void* q, int64_t q_sb, int64_t q_ss, const void* k, int64_t k_sb, int64_t k_ss, const void* v, int64_t v_sb,
+                 int64_t v_ss, const void* o, int64_t o_sb, int64_t o_ss, const void* d_o, int64_t do_sb, int64_t do_ss, const float* lse,
+                 float* delta /* fp32 [B,H,S] workspace */, void* dq, int64_t dq_sb, int64_t dq_ss, void* dk, int64_t dk_sb, int64_t dk_ss,
+                 void* dv, int64_t dv_sb, int64_t dv_ss, const int* doc_ids, const int* prefix_len, const void* flags, int64_t B,
+                 int64_t S, int64_t H, int64_t KVH, int64_t head_dim, float scale, llx_stream_t s);
+
+/* ---- RoPE: apply_rope at modelling/llama.py:63-73 (in place on the first `nheads` 128-wide heads of each row;
+ *      table fp32 [S,64,2] from build_rope :54-60); backward = rotation by -theta. ----------------------------- */
+int llx_rope(const void* x, int64_t x_sb, int64_t x_ss, void* y, int64_t y_sb, int64_t y_ss, const float* table, int64_t B, int64_t S,
+             int64_t nheads, int64_t head_dim, int backward, llx_stream_t s);
+
+/* ---- SwiGLU: silu(w1 x) * w3 x at modelling/llama.py:152 --------------------------------------------------------- */
+int llx_swiglu_fwd(const void* g, int64_t g_ld, const void* u, int64_t u_ld, void* h, int64_t h_ld, int64_t rows, int64_t cols, llx_stream_t s);
+int llx_swiglu_bwd(const void* dh, int64_t dh_ld, const void* g, int64_t g_ld, const void* u, int64_t u_ld, void* dg, int64_t dg_ld,
+                   void* du, int64_t du_ld, int64_t rows, int64_t cols, llx_stream_t s);
+
+/* ---- embedding: nn.Embedding at modelling/llama.py:180,206 / modelling/audio.py:49; strided destination lets the
+ *      gather land behind the audio prefix (replaces torch.cat at modelling/audio.py:63). ------------------------- */
+int llx_embedding_fwd(const int64_t* ids, const void* table, void* out, int64_t n_tok, int64_t dim, int64_t vocab, int64_t tok_per_batch,
+                      int64_t out_sb, int64_t out_ss, llx_stream_t s);
+int llx_embedding_bwd(const int64_t* ids, const void* dy, float* dtable_f32, int64_t n_tok, int64_t dim, int64_t vocab,
+                      int64_t tok_per_batch, int64_t dy_sb, int64_t dy_ss, llx_stream_t s);
+
+/* ---- fused cross-entropy: F.cross_entropy(logits.float(), labels) at modelling/llama.py:218, modelling/audio.py:76
+ *      (ignore_index -100, mean).  dlogits may alias logits (nullable = forward only). --------------------------- */
+int64_t llx_ce_workspace_bytes(int64_t T);
+int llx_ce_fwd_bwd(const void* logits, int64_t ld, void* dlogits, int64_t dld, const int64_t* labels, float* loss, void* workspace,
+                   int64_t T, int64_t V, llx_stream_t s);
+
+/* ---- LoRA skinny contractions (modelling/lora.py:43 and its autograd): T = X.W^T -> [M,64] zero padded;
+ *      G = s * U^T.Y with fp32 split partials (deterministic). --------------------------------------------------- */
+int llx_skinny_nt(const void* X, int64_t ldx, const void* W, int64_t ldw, void* out, int64_t M, int64_t K, int64_t R, llx_stream_t s);
+int64_t llx_skinny_tn_workspace_bytes(int64_t M, int64_t N, int64_t R);
+int llx_skinny_tn(const void* U, const void* Y, int64_t ldy, void* out, int64_t out_ld, int64_t M, int64_t N, int64_t R, float scale,
+                  int transpose_out, int accumulate, void* workspace, llx_stream_t s);
+int llx_pad64(const void* in, int64_t ld, void* out, int64_t R, int64_t C, float scale, int transpose, llx_stream_t s);
+
+/* ---- small utilities of the backward pass ---------------------------------------------------------------------- */
+int llx_scale(const void* x, int64_t x_ld, void* y, int64_t y_ld, const float* dev_scalar, float host_scale, const void* colscale,
+              int64_t rows, int64_t cols, llx_stream_t s);   /* (g * scale) of subclasses/int8.py:127; loss-scale of dX */
+int llx_add(const void* x, const void* y, void* z, int64_t n, llx_stream_t s);   /* residual joins (modelling/llama.py:172-173) */
+int llx_transpose(const void* in, int64_t in_ld, void* out, int64_t out_ld, int64_t R, int64_t C, int src_is_i8, llx_stream_t s);
+int llx_i8_to_bf16(const void* in, void* out, int64_t n, llx_stream_t s);         /* int_data.T.to(dtype) of subclasses/int8.py:118 */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LLX_H */

@@ -1,0 +1,110 @@
+"""Host-side batch construction and step schedule of the reference's training scripts (the integer contracts M1-M4
+of SURVEY 8a).  Pure host code: index / label / mask tensors are bit-exact with the reference's iterators.
+
+  pad_batch            <- _data_iter_padding batch body          (train_metamathqa.py:38-46)
+  pack_documents       <- _data_iter_document_mask                (train_metamathqa.py:51-83), yields doc_ids for MaskSpec
+  prepare_audio_batch  <- LibriSpeech._prepare_batch              (train_librispeech.py:68-86)
+  LRScheduler          <- train_utils.py:38-66
+"""
+from __future__ import annotations
+
+import math
+from typing import Iterable, Iterator, Sequence
+
+import torch
+import torch.nn.functional as F
+from torch import Tensor
+
+
+def next_multiple(x: int, n: int) -> int:
+    return -(-x // n) * n
+
+
+def pad_batch(tokens_batch: Sequence[Tensor], seq_len_multiple: int = 256) -> tuple[Tensor, Tensor]:
+    rows = len(tokens_batch)
+    width = max(next_multiple(t.shape[0] - 1, seq_len_multiple) for t in tokens_batch)
+    inputs = torch.zeros(rows, width, dtype=torch.int64)
+    labels = torch.full((rows, width), -100, dtype=torch.int64)
+    for r, t in enumerate(tokens_batch):
+        n = t.shape[0] - 1
+        inputs[r, :n], labels[r, :n] = t[:-1], t[1:]
+    return inputs, labels
+
+
+def padding_iterator(tokens_list: list[Tensor], batch_size: int, seq_len_multiple: int = 256, generator=None):
+    """Endless shuffled batches (inputs, labels, None), as _data_iter_padding yields them (host tensors)."""
+    n = len(tokens_list)
+    while True:
+        order = torch.randperm(n, generator=generator).tolist()
+        tokens_list = [tokens_list[i] for i in order]
+        for i in range(0, n - batch_size + 1, batch_size):
+            yield (*pad_batch(tokens_list[i : i + batch_size], seq_len_multiple), None)
+
+
+class _PackState:
+    def __init__(self, seq_len: int):
+        self.seq_len, self.fill, self.doc_idx = seq_len, 0, 0  # doc_idx is never reset (reference quirk, :56/:83)
+        self.fresh()
+
+    def fresh(self):
+        self.inputs = torch.zeros(self.seq_len, dtype=torch.int64)
+        self.labels = torch.full((self.seq_len,), -100, dtype=torch.int64)
+        self.doc_ids = torch.zeros(self.seq_len, dtype=torch.int64)  # re-zeroed per buffer: the unused tail carries id 0
+        self.fill = 0
+
+
+def pack_documents(docs: Iterable[Tensor], seq_len: int, state: _PackState | None = None) -> Iterator[tuple[Tensor, Tensor, Tensor]]:
+    """Greedy packing of shifted documents into [seq_len] buffers; yields (inputs, labels, doc_ids) on overflow."""
+    st = state or _PackState(seq_len)
+    for tokens in docs:
+        if st.fill + len(tokens) - 1 > seq_len:
+            yield st.inputs, st.labels, st.doc_ids
+            st.fresh()
+        n = len(tokens) - 1
+        sl = slice(st.fill, st.fill + n)
+        st.inputs[sl], st.labels[sl], st.doc_ids[sl] = tokens[:-1], tokens[1:], st.doc_idx
+        st.fill += n
+        st.doc_idx += 1
+
+
+def document_mask_iterator(tokens_list: list[Tensor], seq_len: int, generator=None):
+    """Endless (inputs[1,S], labels[1,S], MaskSpec(doc_ids)) batches, as _data_iter_document_mask yields them."""
+    from .kernels import MaskSpec
+
+    st = _PackState(seq_len)
+    while True:
+        order = torch.randperm(len(tokens_list), generator=generator).tolist()
+        tokens_list = [tokens_list[i] for i in order]
+        for inputs, labels, doc_ids in pack_documents(tokens_list, seq_len, st):
+            yield inputs.view(1, -1), labels.view(1, -1), MaskSpec(doc_ids=doc_ids.clone())
+
+
+def prepare_audio_batch(batch: Sequence[tuple[Tensor, list[int]]], audio_length: int, seq_len_multiple: int, pad_id: int):
+    audios, toks = zip(*batch)
+    audio = torch.stack([F.pad(a, (0, audio_length - a.shape[0])) for a in audios])
+    width = math.ceil(max(len(t) for t in toks) / seq_len_multiple) * seq_len_multiple
+    tokens = torch.tensor([list(t) + [pad_id] * (width - len(t)) for t in toks])
+    labels = torch.tensor([list(t[1:]) + [-100] * (width - len(t) + 1) for t in toks])
+    return audio, tokens, labels
+
+
+class LRScheduler:
+    """Trapezoid: linear warm-up to lr over n_steps*warmup, flat, linear decay over the last n_steps*decay."""
+
+    def __init__(self, lr: float, n_steps: int, warmup: float, decay: float) -> None:
+        self.lr, self.t1, self.t2, self.t3 = lr, int(n_steps * warmup), int(n_steps * (1 - decay)), n_steps
+
+    def get_lr(self, step: int) -> float:
+        if step < self.t1:
+            return self.lr * step / self.t1
+        if step < self.t2 or step >= self.t3:
+            return self.lr
+        return self.lr * (self.t3 - step) / (self.t3 - self.t2)
+
+    def set_lr(self, optim: torch.optim.Optimizer, step: int):
+        lr = self.get_lr(step)
+        for group in optim.param_groups:
+            if isinstance(group["lr"], Tensor):
+                group["lr"].fill_(lr)
+            else:
+                group["lr"] = lr

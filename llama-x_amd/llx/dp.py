@@ -26,11 +26,11 @@ class GradBuckets:
         self.buckets: list[dict] = []
         cur, cur_n = [], 0
         for p in params:
-            cur.append(p)
-            cur_n += p.numel()
-            if cur_n >= target:
+            if cur and cur_n + p.numel() > target and len(self.buckets) < n_buckets - 1:
                 self.buckets.append(self._make(cur))
                 cur, cur_n = [], 0
+            cur.append(p)
+            cur_n += p.numel()
         if cur:
             self.buckets.append(self._make(cur))
         self._handles = []

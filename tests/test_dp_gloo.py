@@ -1,0 +1,75 @@
+"""CPU, world_size 2 over gloo: the data-parallel gradient exchange (llx/dp.py) averages trainable gradients across ranks
+through flat bucket buffers, equals the single-process gradient on the concatenated batch, and skips the exchange on
+non-final micro-batches of gradient accumulation."""
+import os
+import socket
+import sys
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, os.path.join(ROOT, "llama-x_amd"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from llx.dp import GradBuckets
+
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.Tanh(), torch.nn.Linear(16, 4), torch.nn.Linear(4, 1))
+    model[2].weight.requires_grad_(False)  # frozen parameters take no part in the exchange
+    buckets = GradBuckets(model, n_buckets=2)
+    assert len(buckets.buckets) >= 2
+    assert all(p.grad.data_ptr() >= b["flat"].data_ptr() for b in buckets.buckets for p in b["params"])
+    data = torch.arange(4 * 8, dtype=torch.float32).view(4, 8) / 10.0
+    x = data[rank * 2 : rank * 2 + 2]
+    # step 1: plain
+    model(x).sum().backward()
+    buckets.finish()
+    got = {n: p.grad.clone() for n, p in model.named_parameters() if p.requires_grad}
+    # reference: mean over ranks of per-rank grads == grad of (sum over all 4 rows) / world
+    ref_model = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.Tanh(), torch.nn.Linear(16, 4), torch.nn.Linear(4, 1))
+    ref_model.load_state_dict(model.state_dict())
+    (ref_model(data).sum() / world).backward()
+    ok = all(torch.allclose(got[n], p.grad, atol=1e-6) for n, p in ref_model.named_parameters() if n in got)
+    # step 2: gradient accumulation, exchange only on the last micro-batch
+    buckets.zero_grad()
+    buckets.sync_enabled = False
+    model(x).sum().backward()
+    buckets.finish()
+    local_only = model[0].weight.grad.clone()
+    buckets.sync_enabled = True
+    model(x).sum().backward()
+    buckets.finish()
+    acc = model[0].weight.grad.clone()
+    ref_model.zero_grad()
+    (2 * ref_model(data).sum() / world).backward()
+    ok2 = torch.allclose(acc, ref_model[0].weight.grad, atol=1e-5)
+    q.put((rank, bool(ok), bool(ok2), float(local_only.abs().sum())))
+    dist.destroy_process_group()
+
+
+def test_grad_buckets_world2():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(r[1] for r in res), f"averaged gradients differ from the single-process reference: {res}"
+    assert all(r[2] for r in res), f"gradient accumulation exchange wrong: {res}"

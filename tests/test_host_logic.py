@@ -1,0 +1,218 @@
+"""CPU: host-side logic of the product and the bit-exact integer contracts (index / label / mask construction)."""
+import math
+
+import pytest
+import torch
+
+from oracle import ref as O
+
+
+# ---------------------------------------------------------------------------------------------- M1 padding iterator
+def test_pad_batch_hand_case():
+    toks = [torch.arange(1, 7), torch.arange(10, 13)]  # lengths 6 and 3 -> n = 5 and 2 ; multiple 4 -> L = 8
+    inputs, labels = O.pad_batch(toks, seq_len_multiple=4)
+    assert inputs.tolist() == [[1, 2, 3, 4, 5, 0, 0, 0], [10, 11, 0, 0, 0, 0, 0, 0]]
+    assert labels.tolist() == [[2, 3, 4, 5, 6, -100, -100, -100], [11, 12, -100, -100, -100, -100, -100, -100]]
+    assert inputs.dtype is torch.int64 and labels.dtype is torch.int64
+    assert O.next_multiple(255, 256) == 256 and O.next_multiple(256, 256) == 256 and O.next_multiple(257, 256) == 512
+
+
+def test_product_data_matches_oracle():
+    from llx import data as D
+
+    toks = [O.randint(f"d{i}", (n,), 1, 1000) for i, n in enumerate((17, 300, 64, 257, 5, 129))]
+    a, b = D.pad_batch(toks[:3], 256), O.pad_batch(toks[:3], 256)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    pa = list(D.pack_documents(toks * 3, 512))
+    pb = list(O.pack_documents(toks * 3, 512))
+    assert len(pa) == len(pb) > 0
+    for x, y in zip(pa, pb):
+        assert all(torch.equal(u, v) for u, v in zip(x, y))
+    batch = [(torch.ones(1000), [1, 5, 6, 7, 2]), (torch.ones(500), [1, 9, 2])]
+    for u, v in zip(D.prepare_audio_batch(batch, 1600, 4, 0), O.prepare_audio_batch(batch, 1600, 4, 0)):
+        assert torch.equal(u, v)
+    for step in range(0, 120, 7):
+        assert D.LRScheduler(1e-3, 100, 0.1, 0.2).get_lr(step) == O.lr_at(step, 1e-3, 100, 0.1, 0.2)
+
+
+# ---------------------------------------------------------------------------------------------- M2 packer + mask
+def test_pack_documents_quirks():
+    docs = [torch.arange(100, 100 + n) for n in (5, 4, 6, 3, 4)]
+    out = list(O.pack_documents(docs, seq_len=8))
+    # doc0 (4 tokens) + doc1 (3) fit in 8; doc2 (5) would overflow (7 + 5 > 8) -> flush
+    inp, lab, ids = out[0]
+    assert inp.tolist() == [100, 101, 102, 103, 100, 101, 102, 0]
+    assert lab.tolist() == [101, 102, 103, 104, 101, 102, 103, -100]
+    assert ids.tolist() == [0, 0, 0, 0, 1, 1, 1, 0]  # unused tail carries id 0 (doc_ids re-zeroed, :75)
+    inp2, lab2, ids2 = out[1]
+    assert ids2.tolist() == [2, 2, 2, 2, 2, 3, 3, 0], "document counter is never reset across buffers (:56,:83)"
+    # flush test is i + len(tokens) - 1 > seq_len: an exact fit does not flush
+    exact = list(O.pack_documents([torch.arange(5), torch.arange(5), torch.arange(3)], seq_len=8))
+    assert exact[0][2].tolist() == [0, 0, 0, 0, 1, 1, 1, 1]
+
+
+def test_document_mask_bits():
+    ids = torch.tensor([0, 0, 0, 1, 1, 0, 0])  # first buffer: tail id 0 shares the first document's id
+    m = O.document_mask(ids)
+    expect = torch.tensor([[int(ids[q] == ids[k] and q >= k) for k in range(7)] for q in range(7)], dtype=torch.bool)
+    assert torch.equal(m, expect)
+    assert m[5, 0] and m[6, 2] and not m[5, 3], "tail rows attend causally to document 0 (SURVEY M2 quirk)"
+    p = O.prefix_lm_mask(5, [2])
+    assert p[0, 0].int().tolist() == [[1, 1, 0, 0, 0], [1, 1, 0, 0, 0], [1, 1, 1, 0, 0], [1, 1, 1, 1, 0], [1, 1, 1, 1, 1]]
+    assert torch.equal(O.causal_mask(4), torch.tril(torch.ones(4, 4, dtype=torch.bool)))
+
+
+# ---------------------------------------------------------------------------------------------- M4 audio batch
+def test_prepare_audio_batch():
+    batch = [(torch.ones(5), [1, 7, 8, 2]), (torch.ones(3), [1, 9, 2, 4, 4, 2])]
+    audio, tokens, labels = O.prepare_audio_batch(batch, audio_length=8, seq_len_multiple=4, pad_id=0)
+    assert audio.shape == (2, 8) and audio[0].tolist() == [1, 1, 1, 1, 1, 0, 0, 0]
+    assert tokens.tolist() == [[1, 7, 8, 2, 0, 0, 0, 0], [1, 9, 2, 4, 4, 2, 0, 0]]
+    assert labels.tolist() == [[7, 8, 2, -100, -100, -100, -100, -100], [9, 2, 4, 4, 2, -100, -100, -100]]
+
+
+def test_lr_schedule():
+    f = lambda s: O.lr_at(s, 1.0, 100, 0.1, 0.2)  # noqa: E731
+    assert f(0) == 0.0 and f(5) == 0.5 and f(10) == 1.0 and f(79) == 1.0 and f(80) == 1.0 and f(90) == 0.5 and f(100) == 1.0
+
+
+# ---------------------------------------------------------------------------------------------- product API surface
+def test_module_api_and_state_dict_names():
+    from modelling import AudioConfig, DoRALinear, Llama, LlamaAudio, LlamaConfig, LoRALinear, apply_linear_adapter_
+
+    assert LlamaConfig._fields == ("embed_dim", "num_layers", "head_dim", "num_heads", "num_kv_heads", "intermediate_dim", "max_seq_len",
+                                   "vocab_size", "attn_dropout", "rope_base", "is_llama3_1", "activation_checkpointing")
+    d = LlamaConfig(64, 1, 128, 1, 1, 128)
+    assert (d.max_seq_len, d.vocab_size, d.attn_dropout, d.rope_base, d.is_llama3_1, d.activation_checkpointing) == (2048, 128256, 0.0, 50000, False, False)
+    assert AudioConfig() == (16000, 512, 400, 160, 128)
+    cfg = LlamaConfig(256, 2, 128, 2, 1, 512, max_seq_len=64, vocab_size=300)
+    m = Llama(cfg)
+    m.build_cache()
+    keys = set(m.state_dict().keys())
+    expect = {"tok_embeddings.weight", "norm.weight", "output.weight"}
+    for i in range(2):
+        expect |= {f"layers.{i}.attention.{w}.weight" for w in ("wq", "wk", "wv", "wo")}
+        expect |= {f"layers.{i}.feed_forward.{w}.weight" for w in ("w1", "w2", "w3")}
+        expect |= {f"layers.{i}.attention_norm.weight", f"layers.{i}.ffn_norm.weight"}
+    assert keys == expect, "rope / caches are non-persistent buffers"
+    assert m.rope.shape == (64, 64, 2) and m.rope.dtype is torch.float32
+    assert all(isinstance(x, torch.nn.Linear) for x in (m.output, m.layers[0].attention.wq, m.layers[0].feed_forward.w2))
+    apply_linear_adapter_(m.layers, "lora", rank=4, alpha=8.0)
+    wq = m.layers[0].attention.wq
+    assert isinstance(wq, LoRALinear) and wq.scale == 2.0 and wq.lora_a.shape == (4, 256) and wq.lora_b.shape == (256, 4)
+    assert not wq.weight.requires_grad and wq.lora_a.requires_grad and float(wq.lora_b.abs().sum()) == 0.0
+    assert not isinstance(m.output, LoRALinear), "only model.layers is adapted (train_metamathqa.py:179)"
+    apply_linear_adapter_(m.output, None)
+    ma = LlamaAudio(cfg)
+    assert {"audio_embed.0.weight", "audio_embed.0.bias", "audio_embed.2.weight", "audio_embed.2.bias"} <= set(ma.state_dict())
+    lin = torch.nn.Linear(16, 8)
+    apply_linear_adapter_(lin, "dora", rank=2)
+    assert isinstance(lin, DoRALinear) and torch.allclose(lin.m, lin.weight.norm(p=2, dim=1))
+    with pytest.raises(KeyError):
+        apply_linear_adapter_(lin, "nope")
+
+
+def test_rope_table_product_matches_oracle():
+    from modelling.llama import LlamaConfig, build_rope, scale_llama3_1_rope
+
+    cfg = LlamaConfig(4096, 1, 128, 32, 8, 14336, max_seq_len=512, rope_base=500000, is_llama3_1=True)
+    assert torch.equal(build_rope(cfg), O.rope_table(O.LLAMA31_8B._replace(max_seq_len=512)))
+    f = 1.0 / (500_000 ** (torch.arange(0, 128, 2, dtype=torch.float32) / 128))
+    assert torch.equal(scale_llama3_1_rope(f), O.llama31_rescale(f))
+
+
+def test_hf_key_rename_and_local_loading(tmp_path):
+    import json
+
+    from modelling.llama import Llama, _rename_hf_key
+
+    assert _rename_hf_key("model.layers.3.self_attn.q_proj.weight") == "layers.3.attention.wq.weight"
+    assert _rename_hf_key("model.layers.0.mlp.down_proj.weight") == "layers.0.feed_forward.w2.weight"
+    assert _rename_hf_key("model.layers.0.post_attention_layernorm.weight") == "layers.0.ffn_norm.weight"
+    assert _rename_hf_key("model.embed_tokens.weight") == "tok_embeddings.weight" and _rename_hf_key("lm_head.weight") == "output.weight"
+    # local checkpoint directory (no network): config.json + safetensors with HF names
+    from safetensors.torch import save_file
+
+    hf_cfg = dict(architectures=["LlamaForCausalLM"], hidden_size=128, num_hidden_layers=1, num_attention_heads=1, num_key_value_heads=1,
+                  intermediate_size=256, vocab_size=64, rope_theta=500000.0, rope_scaling=dict(rope_type="llama3"))
+    (tmp_path / "config.json").write_text(json.dumps(hf_cfg))
+    sd = {"model.embed_tokens.weight": torch.randn(64, 128), "model.norm.weight": torch.ones(128), "lm_head.weight": torch.randn(64, 128),
+          "model.layers.0.input_layernorm.weight": torch.ones(128), "model.layers.0.post_attention_layernorm.weight": torch.ones(128)}
+    for hf, shape in (("self_attn.q_proj", (128, 128)), ("self_attn.k_proj", (128, 128)), ("self_attn.v_proj", (128, 128)),
+                      ("self_attn.o_proj", (128, 128)), ("mlp.gate_proj", (256, 128)), ("mlp.up_proj", (256, 128)), ("mlp.down_proj", (128, 256))):
+        sd[f"model.layers.0.{hf}.weight"] = torch.randn(*shape)
+    save_file(sd, str(tmp_path / "model.safetensors"))
+    m = Llama.from_hf(str(tmp_path), max_seq_len=32)
+    assert m.config.is_llama3_1 and m.config.rope_base == 500000.0 and m.config.max_seq_len == 32
+    assert torch.equal(m.layers[0].feed_forward.w1.weight, sd["model.layers.0.mlp.gate_proj.weight"]) and m.rope.shape == (32, 64, 2)
+
+
+# ---------------------------------------------------------------------------------------------- int8 subclass on the host
+def test_int8_weight_subclass_host_behaviour():
+    from subclasses import Int8LinearWeight, quantize_linear_
+    from subclasses.int8 import quantize_int8_rowwise
+
+    w = O.randn("q_w", (96, 512), 0.05).bfloat16()
+    w[5] = 0
+    q, s = quantize_int8_rowwise(w)
+    qo, so = O.quantize_int8_rowwise(w)
+    assert torch.equal(q, qo) and torch.equal(s, so), "host quantiser is bit-exact with the oracle"
+    t = Int8LinearWeight.from_float(w, dynamic_int8_act=True)
+    assert t.shape == (96, 512) and t.dtype is torch.bfloat16 and t.dynamic_int8_act and t.int_data.dtype is torch.int8
+    assert torch.equal(t.dequantize(), O.int8_dequantize(q, s))
+    names, attrs = t.__tensor_flatten__()
+    assert names == ["int_data", "scale"] and attrs == [True]
+    t2 = Int8LinearWeight.__tensor_unflatten__({"int_data": t.int_data, "scale": t.scale}, attrs)
+    assert torch.equal(t2.int_data, t.int_data) and t2.dynamic_int8_act
+    d = t.detach().clone()
+    assert isinstance(d, Int8LinearWeight) and torch.equal(d.int_data, t.int_data)
+    f = t.to(torch.float32)
+    assert f.scale.dtype is torch.float32 and f.int_data.dtype is torch.int8 and f.dtype is torch.float32
+    dst = torch.zeros(96, 512, dtype=torch.bfloat16)
+    dst.copy_(t)
+    assert torch.equal(dst, t.dequantize())
+    t3 = Int8LinearWeight.from_float(torch.zeros(96, 512, dtype=torch.bfloat16))
+    t3.copy_(w)  # float -> int8 re-quantises
+    assert torch.equal(t3.int_data, q) and torch.equal(t3.scale, s)
+    t3.copy_(t)
+    with pytest.raises(NotImplementedError):
+        torch.add(t, 1)
+    lin = torch.nn.Sequential(torch.nn.Linear(512, 96, bias=False))
+    lin[0].weight.data.copy_(w.float())
+    lin = lin.bfloat16()
+    quantize_linear_(lin, "int8")
+    assert isinstance(lin[0].weight, Int8LinearWeight) and not lin[0].weight.requires_grad
+    sd = lin.state_dict()
+    lin2 = torch.nn.Sequential(torch.nn.Linear(512, 96, bias=False)).bfloat16()
+    quantize_linear_(lin2, "int8")
+    lin2.load_state_dict(sd)  # checkpoint round trip goes through copy_ (train_librispeech.py:200-204)
+    assert torch.equal(lin2[0].weight.int_data, q)
+    quantize_linear_(lin, None)
+    with pytest.raises(KeyError):
+        quantize_linear_(lin, "int4")
+
+
+def test_int8_mm_dequant_meta_and_asserts():
+    from subclasses.int8_mm import int8_mm_dequant
+
+    a = torch.zeros(8, 128, dtype=torch.int8, device="meta")
+    b = torch.zeros(16, 128, dtype=torch.int8, device="meta").T
+    out = int8_mm_dequant(a, b, torch.zeros(8, dtype=torch.bfloat16, device="meta"), torch.zeros(16, dtype=torch.bfloat16, device="meta"))
+    assert out.shape == (8, 16) and out.dtype is torch.bfloat16
+    with pytest.raises(AssertionError):
+        int8_mm_dequant(a.float(), b, torch.zeros(8, device="meta"), torch.zeros(16, device="meta"))
+    with pytest.raises(NotImplementedError):  # no CPU kernel, exactly like the reference
+        int8_mm_dequant(torch.zeros(8, 128, dtype=torch.int8), torch.zeros(128, 16, dtype=torch.int8), torch.zeros(8), torch.zeros(16))
+
+
+def test_product_fails_loudly_without_gpu():
+    """The product path has no CPU / eager fallback: CPU tensors raise instead of silently computing elsewhere."""
+    from llx._lib import LlxError
+    from modelling import Llama, LlamaConfig
+
+    m = Llama(LlamaConfig(128, 1, 128, 1, 1, 256, max_seq_len=32, vocab_size=64)).bfloat16()
+    m.build_cache()
+    with pytest.raises(LlxError):
+        m(torch.zeros(1, 8, dtype=torch.int64))
+    with pytest.raises(LlxError):
+        m.layers[0].attention.wq(torch.zeros(1, 8, 128, dtype=torch.bfloat16))
