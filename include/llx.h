@@ -103,6 +103,17 @@ int llx_skinny_tn(const void* U, const void* Y, int64_t ldy, void* out, int64_t 
                   int transpose_out, int accumulate, void* workspace, llx_stream_t s);
 int llx_pad64(const void* in, int64_t ld, void* out, int64_t R, int64_t C, float scale, int transpose, llx_stream_t s);
 
+/* ---- audio front end (modelling/audio.py:26-36,53-60): MelSpectrogram(n_fft 512, win 400, hop 160, 128 slaney mels,
+ *      power 2, centre/reflect) -> log10/clip/CMN -> bf16 time-major padded features; exact-erf GELU; conv k=3 helpers.
+ *      twiddle fp32 [512][2], window fp32 [512], fbank fp32 [257][n_mels] are host-built constants. --------------- */
+int llx_mel_spectrogram(const float* audio, int64_t B, int64_t L, const float* twiddle, const float* window, const float* fbank, float* mel,
+                        int64_t n_frames, int64_t hop, int64_t n_mels, llx_stream_t s);
+int llx_logmel_cmn(const float* mel, void* feat /* bf16 [B, n_frames+1, n_mels] */, int64_t B, int64_t n_frames, int64_t n_mels, llx_stream_t s);
+int llx_gelu_fwd(const void* z, int64_t z_ld, void* y, int64_t y_ld, int64_t rows, int64_t cols, llx_stream_t s);
+int llx_gelu_bwd(const void* dy, int64_t dy_ld, const void* z, int64_t z_ld, void* dz, int64_t dz_ld, int64_t rows, int64_t cols, llx_stream_t s);
+int llx_col2im3(const void* dA, void* dpad, int64_t M, int64_t C, int64_t P, int64_t stride, llx_stream_t s);
+int llx_conv_w_reorder(const void* in, void* out, int64_t D, int64_t C, int to_gemm, llx_stream_t s);
+
 /* ---- small utilities of the backward pass ---------------------------------------------------------------------- */
 int llx_scale(const void* x, int64_t x_ld, void* y, int64_t y_ld, const float* dev_scalar, float host_scale, const void* colscale,
               int64_t rows, int64_t cols, llx_stream_t s);   /* (g * scale) of subclasses/int8.py:127; loss-scale of dX */

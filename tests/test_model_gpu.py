@@ -157,3 +157,71 @@ def test_three_step_trajectory(cuda):
         losses.append(loss.item())
     for a, b in zip(losses, ref_losses):
         assert abs(a - b) < 5e-3 * max(1.0, abs(b)), (losses, ref_losses)
+
+
+# ------------------------------------------------------------------------------------------------- audio (config C3 shape)
+def test_mel_spectrogram_kernel(cuda):
+    """K15: device mel vs the oracle's torch.stft restatement (itself cross-checked to 3.7e-6 against transformers.audio_utils;
+    torchaudio absent => parity unpinned against the reference proper).  fp32 direct DFT vs FFT: 1e-4 of the spectrum's peak."""
+    from llx.audio_ops import MelSpectrogram, logmel_cmn_padded
+
+    audio = O.uniform("audio", (2, 16000), -0.1, 0.1)
+    audio[1, 8000:] = 0.0  # silence exercises the 1e-12 clip
+    ref = O.mel_spectrogram(audio)
+    ms = MelSpectrogram().to(cuda)
+    mel = ms(audio.to(cuda))
+    assert mel.shape == ref.shape == (2, 128, 101)
+    torch.testing.assert_close(mel.cpu(), ref, atol=1e-4 * ref.abs().max().item(), rtol=1e-3)
+    feat = logmel_cmn_padded(mel).cpu().float()
+    rf = O.log_mel_cmn(ref).transpose(1, 2)  # [B, T, n_mels]
+    assert feat.shape == (2, 102, 128) and feat[:, 0].abs().sum() == 0 and feat[:, -1].abs().sum() == 0
+    # bf16 storage of values up to ~|12|: half an ulp = 0.03; compare where the mel energy is above the fp32 noise floor
+    strong = (ref[..., :-1] > 1e-9 * ref.max()).transpose(1, 2)
+    assert ((feat[:, 1:-1] - rf).abs()[strong]).max() < 0.07
+
+
+def test_audio_model_loss_and_conv_grads(cuda):
+    p = O.init_params(CFG, audio=True)
+    pb, pf = bf16_params(p)
+    audio = O.uniform("audio", (1, 32000), -0.1, 0.1)  # 2 s -> 201 frames -> 200 -> 100 audio tokens
+    tokens, labels = _data(1, 128)
+    train = [k for k in pf if k.startswith("audio_embed")]
+    pr = {k: (v.clone().requires_grad_() if k in train else v) for k, v in pf.items()}
+    mel = O.mel_spectrogram(audio)
+    ref_logits = O.llama_audio_forward(None, tokens, pf, CFG, mel=mel)
+    ref = O.llama_audio_forward(None, tokens, pr, CFG, mel=mel, labels=labels)
+    ref.backward()
+    model = build_model(CFG, pb, cuda, audio=True)
+    for n, q in model.named_parameters():
+        q.requires_grad_(n.startswith("audio_embed"))
+    with torch.no_grad():
+        logits = model(audio.to(cuda), tokens.to(cuda))
+    assert logits.shape == ref_logits.shape == (1, 128, CFG.vocab_size)
+    _close(logits.float().cpu(), ref_logits, 0.04, "audio logits")
+    loss = model(audio.to(cuda), tokens.to(cuda), labels=labels.to(cuda))
+    loss.backward()
+    assert abs(loss.item() - ref.item()) < 3e-3 * max(1.0, abs(ref.item())), (loss.item(), ref.item())
+    for name, q in model.named_parameters():
+        if q.requires_grad:
+            _close(q.grad.float().cpu(), pr[name].grad, 0.06, name)
+    # text-only call of the audio model takes the plain embedding path (audio=None, modelling/audio.py:51)
+    with torch.no_grad():
+        t_only = model(None, tokens.to(cuda))
+    _close(t_only.float().cpu(), O.llama_forward(tokens, pf, CFG), 0.03, "audio model, audio=None")
+
+
+def test_audio_prefix_lm_mask(cuda):
+    """P1 end to end: prefix-LM over [audio ; text] with P = number of audio tokens."""
+    from modelling.llama import MaskSpec
+
+    p = O.init_params(CFG, audio=True)
+    pb, pf = bf16_params(p)
+    audio = O.uniform("audio", (1, 32000), -0.1, 0.1)
+    tokens, labels = _data(1, 156)  # 100 audio + 156 text = 256
+    mel = O.mel_spectrogram(audio)
+    mask = O.prefix_lm_mask(256, [100])
+    ref = O.llama_audio_forward(None, tokens, pf, CFG, mel=mel, labels=labels, mask=mask)
+    model = build_model(CFG, pb, cuda, audio=True)
+    with torch.no_grad():
+        loss = model(audio.to(cuda), tokens.to(cuda), labels=labels.to(cuda), block_mask=MaskSpec(prefix_len=torch.tensor([100])))
+    assert abs(loss.item() - ref.item()) < 3e-3 * max(1.0, abs(ref.item())), (loss.item(), ref.item())
