@@ -66,9 +66,10 @@ int llx_attn_tile_flags(const int* doc_ids, const int* prefix_len, void* flags, 
 int llx_attn_fwd(const void* q, int64_t q_sb, int64_t q_ss, const void* k, int64_t k_sb, int64_t k_ss, const void* v, int64_t v_sb,
                  int64_t v_ss, void* o, int64_t o_sb, int64_t o_ss, float* lse, const int* doc_ids, const int* prefix_len,
                  const void* flags, int64_t B, int64_t S, int64_t H, int64_t KVH, int64_t head_dim, float scale, llx_stream_t s);
+int64_t llx_attn_bwd_workspace_bytes(int64_t B, int64_t S, int64_t H, int64_t KVH); /* delta + per-head dK/dV partials */
 int llx_attn_bwd(const void* q, int64_t q_sb, int64_t q_ss, const void* k, int64_t k_sb, int64_t k_ss, const void* v, int64_t v_sb,
                  int64_t v_ss, const void* o, int64_t o_sb, int64_t o_ss, const void* d_o, int64_t do_sb, int64_t do_ss, const float* lse,
-                 float* delta /* fp32 [B,H,S] workspace */, void* dq, int64_t dq_sb, int64_t dq_ss, void* dk, int64_t dk_sb, int64_t dk_ss,
+                 float* delta /* fp32 workspace, llx_attn_bwd_workspace_bytes() */, void* dq, int64_t dq_sb, int64_t dq_ss, void* dk, int64_t dk_sb, int64_t dk_ss,
                  void* dv, int64_t dv_sb, int64_t dv_ss, const int* doc_ids, const int* prefix_len, const void* flags, int64_t B,
                  int64_t S, int64_t H, int64_t KVH, int64_t head_dim, float scale, llx_stream_t s);
 

@@ -383,9 +383,207 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const AttnBwdArgs 
   }
 }
 
+
+// ------------------------------------------------------------------------------------------ dK, dV  (v2)
+// As v1 (a wave owns 32 keys, K/V fragments in registers, dK^T/dV^T in 128 accumulator registers) but one workgroup
+// handles ONE query head of the KV group: 4x the workgroups, heaviest key blocks dispatched first under the causal
+// mask, two workgroups per CU (<= 256 registers) so one wave's softmax VALU overlaps its SIMD partner's MFMAs.
+// The G per-head fp32 partials are summed by attn_dkv_reduce_kernel (deterministic, no atomics).
+#define DKV2_KEYS 128
+
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv2_kernel(const AttnBwdArgs a, float* __restrict__ part) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nqb = (a.S + BQ - 1) / BQ, nkt = (a.S + BKV - 1) / BKV;
+  const int nqt = (a.S + DKV_QT - 1) / DKV_QT;
+  const int G = a.H / a.KVH;
+  // 1-D grid, key block slowest: the heaviest blocks (lowest keys under a causal mask) are dispatched first
+  int id = blockIdx.x;
+  const int per_kb = a.B * a.KVH * G;
+  const int kblk = id / per_kb;
+  id -= kblk * per_kb;
+  const int b = id / (a.KVH * G);
+  id -= b * (a.KVH * G);
+  const int kvh = id / G, g = id % G;
+  const int h = kvh * G + g;
+  const int r = lane & 31, hh = lane >> 5;
+  const int key = kblk * DKV2_KEYS + wave * 32 + r;
+  const int krow = min(key, a.S - 1);
+  const int my_kt = 2 * kblk + (wave >> 1);
+
+  bf16x8_t kf[8], vf[8];
+  {
+    const bf16_t* kp = a.k + (int64_t)b * a.k_sb + (int64_t)krow * a.k_ss + kvh * HD + 8 * hh;
+    const bf16_t* vp = a.v + (int64_t)b * a.v_sb + (int64_t)krow * a.v_ss + kvh * HD + 8 * hh;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      kf[ks] = *reinterpret_cast<const bf16x8_t*>(kp + 16 * ks);
+      vf[ks] = *reinterpret_cast<const bf16x8_t*>(vp + 16 * ks);
+    }
+  }
+  const int key_doc = a.doc_ids ? a.doc_ids[(int64_t)b * a.S + krow] : 0;
+  const int my_prefix = a.prefix_len ? a.prefix_len[b] : 0;
+
+  const int qt_first = a.flags ? 0 : (kblk * DKV2_KEYS) / DKV_QT;
+  auto block_class = [&](int qt, int kt) -> int {
+    if (kt >= nkt) return 0;
+    if (a.flags) return a.flags[((int64_t)b * nqb + (qt >> 1)) * nkt + kt];
+    const int q_lo = qt * DKV_QT, q_hi = q_lo + DKV_QT - 1, k_lo = kt * BKV, k_hi = k_lo + BKV - 1;
+    if (k_lo > q_hi) return 0;
+    return (k_hi <= q_lo) ? 2 : 1;
+  };
+  auto next_qt = [&](int qt) {
+    while (qt < nqt && !(qt >= qt_first && (block_class(qt, 2 * kblk) != 0 || block_class(qt, 2 * kblk + 1) != 0))) ++qt;
+    return qt;
+  };
+
+  const int srow_in = lane >> 4, sslot = lane & 15;
+  const bf16_t* qbase = a.q + (int64_t)b * a.q_sb + h * HD;
+  const bf16_t* dbase = a.d_o + (int64_t)b * a.do_sb + h * HD;
+  auto stage = [&](int buf, int qt) {
+    char* sQ = smem + buf * DKV_STAGE_BYTES;
+    char* sD = sQ + TILE_BYTES;
+    char* sL = sD + TILE_BYTES;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = i * 16 + wave * 4 + srow_in;
+      const int qr = min(qt * DKV_QT + row, a.S - 1);
+      const int c = sslot ^ dual_swz(row);
+      __builtin_amdgcn_global_load_lds((gbl_void*)(qbase + (int64_t)qr * a.q_ss + c * 8), (lds_void*)(sQ + (i * 16 + wave * 4) * 256), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_void*)(dbase + (int64_t)qr * a.do_ss + c * 8), (lds_void*)(sD + (i * 16 + wave * 4) * 256), 16, 0, 0);
+    }
+    if (wave < 2) {
+      const float* src = (wave == 0 ? a.lse : a.delta) + ((int64_t)b * a.H + h) * a.S + min(qt * DKV_QT + lane, a.S - 1);
+      __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(sL + wave * 256), 4, 0, 0);
+    }
+  };
+
+  f32x16_t dk[4], dv[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { dk[i][e] = 0.f; dv[i][e] = 0.f; }
+
+  int qt = next_qt(0);
+  if (qt < nqt) stage(0, qt);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int cur = 0;
+  while (qt < nqt) {
+    const int qtn = next_qt(qt + 1);
+    if (qtn < nqt) stage(cur ^ 1, qtn);
+    const char* sQ = smem + cur * DKV_STAGE_BYTES;
+    const char* sD = sQ + TILE_BYTES;
+    const float* sL = reinterpret_cast<const float*>(sD + TILE_BYTES);
+    int cls = block_class(qt, my_kt);
+    if (cls == 2 && (qt * DKV_QT + DKV_QT > a.S)) cls = 1;
+    if (cls != 0) {
+#pragma unroll
+      for (int qb32 = 0; qb32 < 2; ++qb32) {
+        f32x16_t st, dp;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { st[e] = 0.f; dp[e] = 0.f; }
+        const int row = qb32 * 32 + r;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+          st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(sQ, row, ks, hh), kf[ks], st, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(sD, row, ks, hh), vf[ks], dp, 0, 0, 0);
+        }
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const int ql = qb32 * 32 + 8 * g4 + 4 * hh;
+          const f32x4_t l4 = *reinterpret_cast<const f32x4_t*>(sL + ql);
+          const f32x4_t d4 = *reinterpret_cast<const f32x4_t*>(sL + 64 + ql);
+#pragma unroll
+          for (int e2 = 0; e2 < 4; ++e2) {
+            const int e = 4 * g4 + e2;
+            const float lse = (l4[e2] == -INFINITY) ? 0.f : l4[e2];
+            float p = __builtin_amdgcn_exp2f(st[e] * a.scale_log2 - lse);
+            if (cls != 2) {
+              const int qi = qt * DKV_QT + ql + e2;
+              bool ok = (qi < a.S) && (key < a.S) && (key <= qi || key < my_prefix);
+              if (a.doc_ids) ok = ok && (a.doc_ids[(int64_t)b * a.S + min(qi, a.S - 1)] == key_doc);
+              p = ok ? p : 0.f;
+            }
+            st[e] = p;
+            dp[e] = p * (dp[e] - d4[e2]);
+          }
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          bf16x8_t pb, dsb;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { pb[j] = (__bf16)st[8 * s2 + j]; dsb[j] = (__bf16)dp[8 * s2 + j]; }
+#pragma unroll
+          for (int db = 0; db < 4; ++db) {
+            dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(sD, qb32 * 32 + s2 * 16, db, lane), pb, dv[db], 0, 0, 0);
+            dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(sQ, qb32 * 32 + s2 * 16, db, lane), dsb, dk[db], 0, 0, 0);
+          }
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    cur ^= 1;
+    qt = qtn;
+  }
+
+  // fp32 partials: part[(g*2 + which) * B*S*KVH*128 + ((b*S + key)*KVH + kvh)*128 + d], which = 0 dK (unscaled), 1 dV
+  const int64_t plane = (int64_t)a.B * a.S * a.KVH * HD;
+  if (key < a.S) {
+    float* pk = part + (int64_t)(g * 2 + 0) * plane + (((int64_t)b * a.S + key) * a.KVH + kvh) * HD;
+    float* pv = part + (int64_t)(g * 2 + 1) * plane + (((int64_t)b * a.S + key) * a.KVH + kvh) * HD;
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int d = 32 * db + 8 * g4 + 4 * hh;
+        *reinterpret_cast<f32x4_t*>(pk + d) = f32x4_t{dk[db][4 * g4], dk[db][4 * g4 + 1], dk[db][4 * g4 + 2], dk[db][4 * g4 + 3]};
+        *reinterpret_cast<f32x4_t*>(pv + d) = f32x4_t{dv[db][4 * g4], dv[db][4 * g4 + 1], dv[db][4 * g4 + 2], dv[db][4 * g4 + 3]};
+      }
+  }
+}
+
+// dk = bf16(scale * sum_g partK[g]) ; dv = bf16(sum_g partV[g]);  8 elements per thread.
+__global__ void attn_dkv_reduce_kernel(const AttnBwdArgs a, const float* __restrict__ part) {
+  const int G = a.H / a.KVH;
+  const int64_t plane = (int64_t)a.B * a.S * a.KVH * HD;
+  const int64_t i8 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+  if (i8 >= plane) return;
+  const int d = (int)(i8 % HD);
+  const int64_t row = i8 / HD;  // (b*S + key)*KVH + kvh
+  const int kvh = (int)(row % a.KVH);
+  const int64_t bs = row / a.KVH;
+  const int key = (int)(bs % a.S);
+  const int64_t b = bs / a.S;
+  float sk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int g = 0; g < G; ++g) {
+    const float* pk = part + (int64_t)(g * 2 + 0) * plane + i8;
+    const float* pv = part + (int64_t)(g * 2 + 1) * plane + i8;
+    const f32x4_t k0 = *reinterpret_cast<const f32x4_t*>(pk), k1 = *reinterpret_cast<const f32x4_t*>(pk + 4);
+    const f32x4_t v0 = *reinterpret_cast<const f32x4_t*>(pv), v1 = *reinterpret_cast<const f32x4_t*>(pv + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { sk[e] += k0[e]; sk[4 + e] += k1[e]; sv[e] += v0[e]; sv[4 + e] += v1[e]; }
+  }
+  u32x4_t ok, ov;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    ok[e] = pack_bf2(sk[2 * e] * a.scale, sk[2 * e + 1] * a.scale);
+    ov[e] = pack_bf2(sv[2 * e], sv[2 * e + 1]);
+  }
+  *reinterpret_cast<u32x4_t*>(a.dk + b * a.dk_sb + (int64_t)key * a.dk_ss + kvh * HD + d) = ok;
+  *reinterpret_cast<u32x4_t*>(a.dv + b * a.dv_sb + (int64_t)key * a.dv_ss + kvh * HD + d) = ov;
+}
+
 static bool g_bwd_attr = false;
 
-// delta: fp32 [B,H,S] workspace (written here).  All strides in elements.  flags as in llx_attn_fwd.
+// fp32 workspace of llx_attn_bwd: delta [B,H,S] followed by the dK/dV partials [G][2][B,S,KVH,128].
+extern "C" int64_t llx_attn_bwd_workspace_bytes(int64_t B, int64_t S, int64_t H, int64_t KVH) {
+  return (B * H * S + (H / KVH) * 2 * B * S * KVH * HD) * 4;
+}
+
+// delta: fp32 workspace of llx_attn_bwd_workspace_bytes() bytes.  All strides in elements.  flags as in llx_attn_fwd.
 extern "C" int llx_attn_bwd(const void* q, int64_t q_sb, int64_t q_ss, const void* k, int64_t k_sb, int64_t k_ss, const void* v,
                             int64_t v_sb, int64_t v_ss, const void* o, int64_t o_sb, int64_t o_ss, const void* d_o, int64_t do_sb,
                             int64_t do_ss, const float* lse, float* delta, void* dq, int64_t dq_sb, int64_t dq_ss, void* dk,
@@ -398,12 +596,14 @@ extern "C" int llx_attn_bwd(const void* q, int64_t q_sb, int64_t q_ss, const voi
   LLX_REQUIRE(((q_ss | k_ss | v_ss | o_ss | do_ss | q_sb | k_sb | v_sb | o_sb | do_sb) % 8) == 0, "llx_attn_bwd: input strides must keep 16-byte alignment");
   LLX_REQUIRE(((dq_ss | dk_ss | dv_ss | dq_sb | dk_sb | dv_sb) % 4) == 0, "llx_attn_bwd: output strides must keep 8-byte alignment");
   LLX_REQUIRE(((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o | (uintptr_t)d_o) % 16 == 0, "llx_attn_bwd: unaligned input");
-  LLX_REQUIRE(((uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv) % 8 == 0, "llx_attn_bwd: unaligned output");
+  LLX_REQUIRE(((uintptr_t)dq) % 8 == 0 && ((uintptr_t)dk | (uintptr_t)dv) % 16 == 0 && ((dk_ss | dv_ss | dk_sb | dv_sb) % 8) == 0,
+              "llx_attn_bwd: unaligned output");
   LLX_REQUIRE(!(doc_ids || prefix_len) || flags, "llx_attn_bwd: tile flags required with doc_ids/prefix_len");
   if (!g_bwd_attr) {
     hipError_t e1 = hipFuncSetAttribute((const void*)attn_bwd_dq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DQ_LDS_BYTES);
     hipError_t e2 = hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS_BYTES);
-    if (e1 != hipSuccess || e2 != hipSuccess) { llx_set_error("llx_attn_bwd: cannot raise LDS limit"); return LLX_ERR_LAUNCH; }
+    hipError_t e3 = hipFuncSetAttribute((const void*)attn_bwd_dkv2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS_BYTES);
+    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) { llx_set_error("llx_attn_bwd: cannot raise LDS limit"); return LLX_ERR_LAUNCH; }
     g_bwd_attr = true;
   }
   AttnBwdArgs a;
@@ -417,8 +617,15 @@ extern "C" int llx_attn_bwd(const void* q, int64_t q_sb, int64_t q_ss, const voi
   const int64_t rows = B * S * H;
   hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)cdiv64(rows, 16)), dim3(256), 0, stream, a);
   LLX_LAUNCH_CHECK("llx_attn_bwd(delta)");
-  hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((unsigned)cdiv64(S, 128), (unsigned)KVH, (unsigned)B), dim3(256), DKV_LDS_BYTES, stream, a);
-  LLX_LAUNCH_CHECK("llx_attn_bwd(dkv)");
+  {
+    float* part = delta + B * H * S;
+    const int64_t nkb = cdiv64(S, DKV2_KEYS);
+    hipLaunchKernelGGL(attn_bwd_dkv2_kernel, dim3((unsigned)(nkb * B * H)), dim3(256), DKV_LDS_BYTES, stream, a, part);
+    LLX_LAUNCH_CHECK("llx_attn_bwd(dkv2)");
+    const int64_t plane = B * S * KVH * HD;
+    hipLaunchKernelGGL(attn_dkv_reduce_kernel, dim3((unsigned)cdiv64(plane / 8, 256)), dim3(256), 0, stream, a, (const float*)part);
+    LLX_LAUNCH_CHECK("llx_attn_bwd(dkv reduce)");
+  }
   hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((unsigned)cdiv64(S, BQ), (unsigned)H, (unsigned)B), dim3(256), DQ_LDS_BYTES, stream, a);
   LLX_LAUNCH_CHECK("llx_attn_bwd(dq)");
   return LLX_OK;

@@ -313,7 +313,7 @@ def attn_bwd(q: Tensor, k: Tensor, v: Tensor, o: Tensor, do: Tensor, lse: Tensor
     KVH = k.shape[2]
     for t in (q, k, v, o, do, dq, dk, dv):
         assert t.stride(3) == 1 and t.stride(2) == hd
-    delta = torch.empty(B, H, S, device=q.device, dtype=torch.float32)
+    delta = torch.empty(_lib().llx_attn_bwd_workspace_bytes(B, S, H, KVH) // 4, device=q.device, dtype=torch.float32)  # delta + dK/dV partials
     d = p = fl = None
     if mask is not None:
         mask = mask.prepared(B, S, q.device)
