@@ -130,14 +130,22 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restri
 }
 
 // dw[col] = bf16( sum_p partial[p][col] ), optionally accumulating into an existing bf16 grad.
-__global__ void colsum_partials_kernel(const float* __restrict__ partial, bf16_t* __restrict__ out, int nparts, int dim,
-                                       int accumulate) {
-  const int col = blockIdx.x * blockDim.x + threadIdx.x;
-  if (col >= dim) return;
+// Block = 64 columns x 4 row groups (256 threads): row groups split the partial rows, LDS combines them.
+__global__ __launch_bounds__(256) void colsum_partials_kernel(const float* __restrict__ partial, bf16_t* __restrict__ out, int nparts, int dim,
+                                                              int accumulate) {
+  __shared__ float red[4][64];
+  const int c = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + c;
   float s = 0.f;
-  for (int p = 0; p < nparts; ++p) s += partial[(int64_t)p * dim + col];
-  if (accumulate) s += bf2f(out[col]);
-  out[col] = f2bf(s);
+  if (col < dim)
+    for (int p = grp; p < nparts; p += 4) s += partial[(int64_t)p * dim + col];
+  red[grp][c] = s;
+  __syncthreads();
+  if (grp == 0 && col < dim) {
+    s = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+    if (accumulate) s += bf2f(out[col]);
+    out[col] = f2bf(s);
+  }
 }
 
 extern "C" int llx_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int64_t rows, int64_t dim, float eps,
@@ -176,7 +184,7 @@ extern "C" int llx_rmsnorm_bwd(const void* dy, const void* x, const void* w, con
 #undef L
   LLX_LAUNCH_CHECK("llx_rmsnorm_bwd");
   if (dw) {
-    hipLaunchKernelGGL(colsum_partials_kernel, dim3((unsigned)cdiv64(dim, 256)), dim3(256), 0, stream, part, (bf16_t*)dw, nblk,
+    hipLaunchKernelGGL(colsum_partials_kernel, dim3((unsigned)cdiv64(dim, 64)), dim3(256), 0, stream, part, (bf16_t*)dw, nblk,
                        (int)dim, dw_accumulate);
     LLX_LAUNCH_CHECK("llx_rmsnorm_bwd(colsum)");
   }

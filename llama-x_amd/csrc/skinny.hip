@@ -10,11 +10,15 @@ typedef __attribute__((ext_vector_type(8))) short s16x8_t;
 #define SK_PAD 64  // skinny outputs are [M, 64] bf16, columns >= R are zero (they feed the GEMM K-extension)
 
 // ------------------------------------------------------------------------------------------ NT
-// block = 4 waves = 16 rows of X; the waves interleave over k-steps of 32 and combine through LDS.
+// block = 8 waves = 16 rows of X; the waves interleave over k-steps of 32 (8 loads of 1 KiB in flight per wave, so a
+// CU keeps 64 KiB of HBM reads outstanding with one block resident) and combine their partial tiles through LDS.
+#define SNT_WAVES 8
+#define SNT_UNROLL 8
+
 template <int NB>
-__global__ __launch_bounds__(256) void skinny_nt_kernel(const bf16_t* __restrict__ X, int64_t ldx, const bf16_t* __restrict__ W, int64_t ldw,
-                                                        bf16_t* __restrict__ out, int M, int K, int R) {
-  __shared__ float part[4][16][SK_PAD];
+__global__ __launch_bounds__(SNT_WAVES * 64) void skinny_nt_kernel(const bf16_t* __restrict__ X, int64_t ldx, const bf16_t* __restrict__ W,
+                                                                   int64_t ldw, bf16_t* __restrict__ out, int M, int K, int R) {
+  __shared__ float part[SNT_WAVES][16][SK_PAD];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int m0 = blockIdx.x * 16;
   const int fr = lane & 15, fq = lane >> 4;
@@ -26,8 +30,20 @@ __global__ __launch_bounds__(256) void skinny_nt_kernel(const bf16_t* __restrict
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) acc[nb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   const int nks = K >> 5;
-#pragma unroll 4
-  for (int ks = wave; ks < nks; ks += 4) {
+  int ks = wave;
+  for (; ks + (SNT_UNROLL - 1) * SNT_WAVES < nks; ks += SNT_UNROLL * SNT_WAVES) {
+    bf16x8_t a[SNT_UNROLL];
+#pragma unroll
+    for (int u = 0; u < SNT_UNROLL; ++u) a[u] = *reinterpret_cast<const bf16x8_t*>(xp + (ks + u * SNT_WAVES) * 32);
+#pragma unroll
+    for (int u = 0; u < SNT_UNROLL; ++u)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const bf16x8_t b = *reinterpret_cast<const bf16x8_t*>(wp[nb] + (ks + u * SNT_WAVES) * 32);
+        acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[u], b, acc[nb], 0, 0, 0);
+      }
+  }
+  for (; ks < nks; ks += SNT_WAVES) {
     const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(xp + ks * 32);
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
@@ -40,17 +56,21 @@ __global__ __launch_bounds__(256) void skinny_nt_kernel(const bf16_t* __restrict
 #pragma unroll
     for (int e = 0; e < 4; ++e) part[wave][fq * 4 + e][nb * 16 + fr] = acc[nb][e];
   __syncthreads();
-  // thread t -> row t>>4, cols (t&15)*4..+4
-  const int row = threadIdx.x >> 4, c0 = (threadIdx.x & 15) * 4;
+  // 1024 outputs / 512 threads: thread t -> row t>>5, cols (t&31)*2..+2
+  const int row = threadIdx.x >> 5, c0 = (threadIdx.x & 31) * 2;
   if (m0 + row < M) {
-    float v[4];
+    float v[2];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
+    for (int e = 0; e < 2; ++e) {
       const int c = c0 + e;
-      v[e] = (c < NB * 16 && c < R) ? part[0][row][c] + part[1][row][c] + part[2][row][c] + part[3][row][c] : 0.f;
+      float s = 0.f;
+      if (c < NB * 16 && c < R) {
+#pragma unroll
+        for (int w = 0; w < SNT_WAVES; ++w) s += part[w][row][c];
+      }
+      v[e] = s;
     }
-    u32x2_t pk = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
-    *reinterpret_cast<u32x2_t*>(out + (int64_t)(m0 + row) * SK_PAD + c0) = pk;
+    *reinterpret_cast<uint32_t*>(out + (int64_t)(m0 + row) * SK_PAD + c0) = pack_bf2(v[0], v[1]);
   }
 }
 
@@ -60,7 +80,7 @@ extern "C" int llx_skinny_nt(const void* X, int64_t ldx, const void* W, int64_t 
   LLX_REQUIRE(X && W && out, "llx_skinny_nt: null pointer");
   LLX_REQUIRE(M > 0 && K > 0 && K % 32 == 0 && R > 0 && R <= 64, "llx_skinny_nt: need K%%32==0 and 0<R<=64 (K=%lld R=%lld)", (long long)K, (long long)R);
   LLX_REQUIRE(ldx % 8 == 0 && ldw % 8 == 0 && ((uintptr_t)X | (uintptr_t)W) % 16 == 0 && (uintptr_t)out % 8 == 0, "llx_skinny_nt: alignment");
-  const dim3 grid((unsigned)cdiv64(M, 16)), block(256);
+  const dim3 grid((unsigned)cdiv64(M, 16)), block(SNT_WAVES * 64);
   const int nb = (int)cdiv64(R, 16);
 #define L(N) hipLaunchKernelGGL(skinny_nt_kernel<N>, grid, block, 0, stream, (const bf16_t*)X, ldx, (const bf16_t*)W, ldw, (bf16_t*)out, (int)M, (int)K, (int)R)
   if (nb == 1) L(1); else if (nb == 2) L(2); else L(4);

@@ -19,6 +19,11 @@ class GradBuckets:
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         params = [p for p in model.parameters() if p.requires_grad]
+        self._params = params
+        if self.world == 1:
+            # single replica: nothing to exchange - leave .grad to autograd (no flat views, no accumulate-add kernels)
+            self.buckets, self._handles, self._hooks, self.sync_enabled = [], [], [], True
+            return
         # backward produces gradients roughly in reverse registration order: bucket 0 = last layers
         params = list(reversed(params))
         total = sum(p.numel() for p in params)
@@ -74,5 +79,9 @@ class GradBuckets:
 
     def zero_grad(self):
         """Keep the views, zero the storage (optimizer.zero_grad(set_to_none=True) would drop the views)."""
+        if self.world == 1:
+            for p in self._params:
+                p.grad = None
+            return
         for b in self.buckets:
             b["flat"].zero_()

@@ -30,7 +30,7 @@ def _worker(rank, world, port, q):
     model = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.Tanh(), torch.nn.Linear(16, 4), torch.nn.Linear(4, 1))
     model[2].weight.requires_grad_(False)  # frozen parameters take no part in the exchange
     buckets = GradBuckets(model, n_buckets=2)
-    assert len(buckets.buckets) >= 2
+    assert len(buckets.buckets) >= 2  # world > 1: flat bucket views exist
     assert all(p.grad.data_ptr() >= b["flat"].data_ptr() for b in buckets.buckets for p in b["params"])
     data = torch.arange(4 * 8, dtype=torch.float32).view(4, 8) / 10.0
     x = data[rank * 2 : rank * 2 + 2]
