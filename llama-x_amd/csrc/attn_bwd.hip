@@ -85,6 +85,7 @@ __global__ void attn_delta_kernel(const AttnBwdArgs a) {
 #define DQ_STAGE_BYTES (2 * TILE_BYTES)
 #define DQ_LDS_BYTES (2 * DQ_STAGE_BYTES)
 
+template <bool GENERAL>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -111,11 +112,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnBwdArgs a
   const float my_delta = a.delta[((int64_t)b * a.H + h) * a.S + qrow];
   const float lse_safe = (my_lse == -INFINITY) ? 0.f : my_lse;
 
-  const uint8_t* fl = a.flags ? a.flags + ((int64_t)b * nqb + qb) * nkt : nullptr;
-  const int kt_end = fl ? nkt : min(nkt, (qb * BQ + BQ + BKV - 1) / BKV);
+  const uint8_t* fl = GENERAL ? a.flags + ((int64_t)b * nqb + qb) * nkt : nullptr;
+  const int kt_end = GENERAL ? nkt : min(nkt, (qb * BQ + BQ + BKV - 1) / BKV);
   auto tile_class = [&](int t) -> int {
-    if (fl) return fl[t];
-    return (t * BKV + BKV - 1 <= qb * BQ) ? 2 : 1;
+    if constexpr (GENERAL) return fl[t];
+    else return (t * BKV + BKV - 1 <= qb * BQ) ? 2 : 1;
   };
   auto next_tile = [&](int t) {
     while (t < kt_end && tile_class(t) == 0) ++t;
@@ -144,8 +145,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnBwdArgs a
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int e = 0; e < 16; ++e) dq[i][e] = 0.f;
-  const int my_doc = a.doc_ids ? a.doc_ids[(int64_t)b * a.S + qrow] : 0;
-  const int my_prefix = a.prefix_len ? a.prefix_len[b] : 0;
+  const int* docrow = (GENERAL && a.doc_ids) ? a.doc_ids + (int64_t)b * a.S : nullptr;
+  const int my_doc = docrow ? docrow[qrow] : 0;
+  const int my_prefix = (GENERAL && a.prefix_len) ? a.prefix_len[b] : 0;
 
   int t = next_tile(0);
   if (t < kt_end) stage(0, t);
@@ -161,24 +163,26 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnBwdArgs a
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
       f32x16_t st, dp;
-#pragma unroll
-      for (int e = 0; e < 16; ++e) { st[e] = 0.f; dp[e] = 0.f; }
+      const f32x16_t zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       const int row = kb * 32 + r;
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) {
         bf16x8_t kf = row_frag(sK, row, ks, hh);
-        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], st, 0, 0, 0);
+        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], ks == 0 ? zero : st, 0, 0, 0);
         bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(sV + row * 256 + (((2 * ks + hh) ^ (row & 15)) << 4));
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[ks], dp, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[ks], ks == 0 ? zero : dp, 0, 0, 0);
       }
       // dS^T = P^T * (dP^T - delta)
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        float p = exp2f(st[e] * a.scale_log2 - lse_safe);
+        float p = __builtin_amdgcn_exp2f(__builtin_fmaf(st[e], a.scale_log2, -lse_safe));
         if (cls != 2) {
           const int kk = t * BKV + kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
           bool ok = (kk < a.S) && (kk <= qi || kk < my_prefix);
-          if (a.doc_ids) ok = ok && (a.doc_ids[(int64_t)b * a.S + min(kk, a.S - 1)] == my_doc);
+          if constexpr (GENERAL) {
+            const int kd = docrow ? docrow[min(kk, a.S - 1)] : my_doc;
+            ok = ok && (kd == my_doc);
+          }
           p = ok ? p : 0.f;
         }
         st[e] = p * (dp[e] - my_delta);
@@ -335,7 +339,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const AttnBwdArgs 
           for (int e2 = 0; e2 < 4; ++e2) {
             const int e = 4 * g4 + e2;
             const float lse = (l4[e2] == -INFINITY) ? 0.f : l4[e2];
-            float p = exp2f(st[e] * a.scale_log2 - lse);
+            float p = __builtin_amdgcn_exp2f(__builtin_fmaf(st[e], a.scale_log2, -lse));
             if (cls != 2) {
               const int qi = qt * DKV_QT + ql + e2;
               bool ok = (qi < a.S) && (key < a.S) && (key <= qi || key < my_prefix);
@@ -391,6 +395,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const AttnBwdArgs 
 // The G per-head fp32 partials are summed by attn_dkv_reduce_kernel (deterministic, no atomics).
 #define DKV2_KEYS 128
 
+template <bool GENERAL>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv2_kernel(const AttnBwdArgs a, float* __restrict__ part) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -422,13 +427,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv2_kernel(const AttnBwdArgs
       vf[ks] = *reinterpret_cast<const bf16x8_t*>(vp + 16 * ks);
     }
   }
-  const int key_doc = a.doc_ids ? a.doc_ids[(int64_t)b * a.S + krow] : 0;
-  const int my_prefix = a.prefix_len ? a.prefix_len[b] : 0;
+  const int* docrow = (GENERAL && a.doc_ids) ? a.doc_ids + (int64_t)b * a.S : nullptr;
+  const int key_doc = docrow ? docrow[krow] : 0;
+  const int my_prefix = (GENERAL && a.prefix_len) ? a.prefix_len[b] : 0;
 
-  const int qt_first = a.flags ? 0 : (kblk * DKV2_KEYS) / DKV_QT;
+  const int qt_first = GENERAL ? 0 : (kblk * DKV2_KEYS) / DKV_QT;
   auto block_class = [&](int qt, int kt) -> int {
     if (kt >= nkt) return 0;
-    if (a.flags) return a.flags[((int64_t)b * nqb + (qt >> 1)) * nkt + kt];
+    if constexpr (GENERAL) return a.flags[((int64_t)b * nqb + (qt >> 1)) * nkt + kt];
     const int q_lo = qt * DKV_QT, q_hi = q_lo + DKV_QT - 1, k_lo = kt * BKV, k_hi = k_lo + BKV - 1;
     if (k_lo > q_hi) return 0;
     return (k_hi <= q_lo) ? 2 : 1;
@@ -482,13 +488,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv2_kernel(const AttnBwdArgs
 #pragma unroll
       for (int qb32 = 0; qb32 < 2; ++qb32) {
         f32x16_t st, dp;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) { st[e] = 0.f; dp[e] = 0.f; }
+        const f32x16_t zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         const int row = qb32 * 32 + r;
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
-          st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(sQ, row, ks, hh), kf[ks], st, 0, 0, 0);
-          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(sD, row, ks, hh), vf[ks], dp, 0, 0, 0);
+          st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(sQ, row, ks, hh), kf[ks], ks == 0 ? zero : st, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(sD, row, ks, hh), vf[ks], ks == 0 ? zero : dp, 0, 0, 0);
         }
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
@@ -499,11 +504,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv2_kernel(const AttnBwdArgs
           for (int e2 = 0; e2 < 4; ++e2) {
             const int e = 4 * g4 + e2;
             const float lse = (l4[e2] == -INFINITY) ? 0.f : l4[e2];
-            float p = __builtin_amdgcn_exp2f(st[e] * a.scale_log2 - lse);
+            float p = __builtin_amdgcn_exp2f(__builtin_fmaf(st[e], a.scale_log2, -lse));
             if (cls != 2) {
               const int qi = qt * DKV_QT + ql + e2;
               bool ok = (qi < a.S) && (key < a.S) && (key <= qi || key < my_prefix);
-              if (a.doc_ids) ok = ok && (a.doc_ids[(int64_t)b * a.S + min(qi, a.S - 1)] == key_doc);
+              if constexpr (GENERAL) {
+                const int qd = docrow ? docrow[min(qi, a.S - 1)] : key_doc;
+                ok = ok && (qd == key_doc);
+              }
               p = ok ? p : 0.f;
             }
             st[e] = p;
@@ -600,10 +608,12 @@ extern "C" int llx_attn_bwd(const void* q, int64_t q_sb, int64_t q_ss, const voi
               "llx_attn_bwd: unaligned output");
   LLX_REQUIRE(!(doc_ids || prefix_len) || flags, "llx_attn_bwd: tile flags required with doc_ids/prefix_len");
   if (!g_bwd_attr) {
-    hipError_t e1 = hipFuncSetAttribute((const void*)attn_bwd_dq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DQ_LDS_BYTES);
+    hipError_t e1 = hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, DQ_LDS_BYTES);
+    hipError_t e4 = hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, DQ_LDS_BYTES);
+    hipError_t e5 = hipFuncSetAttribute((const void*)attn_bwd_dkv2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS_BYTES);
     hipError_t e2 = hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS_BYTES);
-    hipError_t e3 = hipFuncSetAttribute((const void*)attn_bwd_dkv2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS_BYTES);
-    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) { llx_set_error("llx_attn_bwd: cannot raise LDS limit"); return LLX_ERR_LAUNCH; }
+    hipError_t e3 = hipFuncSetAttribute((const void*)attn_bwd_dkv2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS_BYTES);
+    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess || e5 != hipSuccess) { llx_set_error("llx_attn_bwd: cannot raise LDS limit"); return LLX_ERR_LAUNCH; }
     g_bwd_attr = true;
   }
   AttnBwdArgs a;
@@ -620,13 +630,15 @@ extern "C" int llx_attn_bwd(const void* q, int64_t q_sb, int64_t q_ss, const voi
   {
     float* part = delta + B * H * S;
     const int64_t nkb = cdiv64(S, DKV2_KEYS);
-    hipLaunchKernelGGL(attn_bwd_dkv2_kernel, dim3((unsigned)(nkb * B * H)), dim3(256), DKV_LDS_BYTES, stream, a, part);
+    if (a.flags) hipLaunchKernelGGL(attn_bwd_dkv2_kernel<true>, dim3((unsigned)(nkb * B * H)), dim3(256), DKV_LDS_BYTES, stream, a, part);
+    else hipLaunchKernelGGL(attn_bwd_dkv2_kernel<false>, dim3((unsigned)(nkb * B * H)), dim3(256), DKV_LDS_BYTES, stream, a, part);
     LLX_LAUNCH_CHECK("llx_attn_bwd(dkv2)");
     const int64_t plane = B * S * KVH * HD;
     hipLaunchKernelGGL(attn_dkv_reduce_kernel, dim3((unsigned)cdiv64(plane / 8, 256)), dim3(256), 0, stream, a, (const float*)part);
     LLX_LAUNCH_CHECK("llx_attn_bwd(dkv reduce)");
   }
-  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((unsigned)cdiv64(S, BQ), (unsigned)H, (unsigned)B), dim3(256), DQ_LDS_BYTES, stream, a);
+  if (a.flags) hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, dim3((unsigned)cdiv64(S, BQ), (unsigned)H, (unsigned)B), dim3(256), DQ_LDS_BYTES, stream, a);
+  else hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, dim3((unsigned)cdiv64(S, BQ), (unsigned)H, (unsigned)B), dim3(256), DQ_LDS_BYTES, stream, a);
   LLX_LAUNCH_CHECK("llx_attn_bwd(dq)");
   return LLX_OK;
 }

@@ -37,6 +37,8 @@ struct AttnFwdArgs {
   float scale_log2;       // softmax scale * log2(e)
 };
 
+// GENERAL = false: pure causal (no doc_ids / prefix_len / tile flags) - the mask is index arithmetic only.
+template <bool GENERAL>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -58,11 +60,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnFwdArgs a) {
   }
 
   // ---- tile schedule
-  const uint8_t* fl = a.flags ? a.flags + ((int64_t)b * nqb + qb) * nkt : nullptr;
-  const int kt_end = fl ? nkt : min(nkt, (qb * BQ + BQ + BKV - 1) / BKV);
+  const uint8_t* fl = GENERAL ? a.flags + ((int64_t)b * nqb + qb) * nkt : nullptr;
+  const int kt_end = GENERAL ? nkt : min(nkt, (qb * BQ + BQ + BKV - 1) / BKV);
   auto tile_class = [&](int t) -> int {
-    if (fl) return fl[t];
-    return (t * BKV + BKV - 1 <= qb * BQ) ? 2 : 1;  // all keys <= first query row of the block => no masking
+    if constexpr (GENERAL) return fl[t];
+    else return (t * BKV + BKV - 1 <= qb * BQ) ? 2 : 1;  // all keys <= first query row of the block => no masking
   };
   auto next_tile = [&](int t) {
     while (t < kt_end && tile_class(t) == 0) ++t;
@@ -96,8 +98,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnFwdArgs a) {
     for (int e = 0; e < 16; ++e) o[i][e] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
 
-  const int my_doc = a.doc_ids ? a.doc_ids[(int64_t)b * a.S + qrow] : 0;
-  const int my_prefix = a.prefix_len ? a.prefix_len[b] : 0;
+  const int* docrow = (GENERAL && a.doc_ids) ? a.doc_ids + (int64_t)b * a.S : nullptr;
+  const int my_doc = docrow ? docrow[qrow] : 0;
+  const int my_prefix = (GENERAL && a.prefix_len) ? a.prefix_len[b] : 0;
 
   // tr-read lane constants: group-local i = lane&15 -> q4 = i>>2 (row in block), p = i&3
   const int tq = (lane & 15) >> 2, tp = lane & 3;
@@ -118,53 +121,59 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnFwdArgs a) {
     f32x16_t st[2];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-      for (int e = 0; e < 16; ++e) st[kb][e] = 0.f;
       const int row = kb * 32 + r;
+      const f32x16_t zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) {
         bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(sK + row * 256 + (((2 * ks + hh) ^ (row & 15)) << 4));
-        st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], st[kb], 0, 0, 0);
+        st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], ks == 0 ? zero : st[kb], 0, 0, 0);
       }
     }
 
-    // ---- scale, mask, online softmax (row statistics are per lane; the partner half-wave holds the other keys)
+    // ---- mask, online softmax in log2 units (row statistics are per lane; the partner half-wave holds the other keys)
     const int cls = tile_class(t);
     float mx = -INFINITY;
+    if (cls != 2) {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int kk = t * BKV + kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+          bool ok = (kk < a.S) && (kk <= qi || kk < my_prefix);
+          if constexpr (GENERAL) {
+            const int kd = docrow ? docrow[min(kk, a.S - 1)] : my_doc;  // branch-free: one (cached) load per key
+            ok = ok && (kd == my_doc);
+          }
+          st[kb][e] = ok ? st[kb][e] : -INFINITY;
+        }
+    }
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        float s = st[kb][e] * a.scale_log2;
-        if (cls != 2) {
-          const int kk = t * BKV + kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
-          bool ok = (kk < a.S) && (kk <= qi || kk < my_prefix);
-          if (a.doc_ids) ok = ok && (a.doc_ids[(int64_t)b * a.S + min(kk, a.S - 1)] == my_doc);
-          s = ok ? s : -INFINITY;
-        }
-        st[kb][e] = s;
-        mx = fmaxf(mx, s);
-      }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      for (int e = 0; e < 16; ++e) mx = fmaxf(mx, st[kb][e]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * a.scale_log2;  // scale > 0: max commutes with the scaling
     const float m_new = fmaxf(m_run, mx);
     const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
-    const float alpha = exp2f(m_run - m_safe);  // m_run = -inf -> 0
     float rs = 0.f;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        float p = exp2f(st[kb][e] - m_safe);
+        const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(st[kb][e], a.scale_log2, -m_safe));  // exp2(-inf) = 0 for masked keys
         st[kb][e] = p;
         rs += p;
       }
     rs += __shfl_xor(rs, 32, 64);
-    l_run = l_run * alpha + rs;
+    if (__builtin_amdgcn_ballot_w64(m_new != m_run) != 0) {  // some row's maximum moved: rescale (wave-uniform branch)
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_safe);  // m_run = -inf -> 0
+      l_run *= alpha;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[i][e] *= alpha;
+    }
+    l_run += rs;
     m_run = m_new;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) o[i][e] *= alpha;
 
     // ---- O^T += V^T.P^T : P^T k-step (kb, s) = accumulator regs 8s..8s+7; element j <-> key 32kb+16s+8(j>>2)+4hh+(j&3)
 #pragma unroll
@@ -261,8 +270,9 @@ extern "C" int llx_attn_fwd(const void* q, int64_t q_sb, int64_t q_ss, const voi
   LLX_REQUIRE(!(doc_ids || prefix_len) || flags, "llx_attn_fwd: tile flags required with doc_ids/prefix_len");
   LLX_REQUIRE(S < (1 << 24), "llx_attn_fwd: S too large");
   if (!g_attn_attr) {
-    hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS_BYTES);
-    if (e != hipSuccess) { llx_set_error("llx_attn_fwd: %s", hipGetErrorString(e)); return LLX_ERR_LAUNCH; }
+    hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS_BYTES);
+    hipError_t e2 = hipFuncSetAttribute((const void*)attn_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS_BYTES);
+    if (e != hipSuccess || e2 != hipSuccess) { llx_set_error("llx_attn_fwd: %s", hipGetErrorString(e != hipSuccess ? e : e2)); return LLX_ERR_LAUNCH; }
     g_attn_attr = true;
   }
   AttnFwdArgs a;
@@ -271,7 +281,8 @@ extern "C" int llx_attn_fwd(const void* q, int64_t q_sb, int64_t q_ss, const voi
   a.doc_ids = doc_ids; a.prefix_len = prefix_len; a.flags = (doc_ids || prefix_len) ? (const uint8_t*)flags : nullptr;
   a.B = (int)B; a.S = (int)S; a.H = (int)H; a.KVH = (int)KVH;
   a.scale_log2 = scale * 1.4426950408889634f;
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)cdiv64(S, BQ), (unsigned)H, (unsigned)B), dim3(256), ATT_LDS_BYTES, stream, a);
+  if (a.flags) hipLaunchKernelGGL(attn_fwd_kernel<true>, dim3((unsigned)cdiv64(S, BQ), (unsigned)H, (unsigned)B), dim3(256), ATT_LDS_BYTES, stream, a);
+  else hipLaunchKernelGGL(attn_fwd_kernel<false>, dim3((unsigned)cdiv64(S, BQ), (unsigned)H, (unsigned)B), dim3(256), ATT_LDS_BYTES, stream, a);
   LLX_LAUNCH_CHECK("llx_attn_fwd");
   return LLX_OK;
 }
