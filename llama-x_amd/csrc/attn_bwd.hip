@@ -5,8 +5,8 @@
 // no atomics.  Three launches:
 //   1. attn_delta_kernel : delta[b,h,q] = sum_d dO.O
 //   2. attn_bwd_dq_kernel: one workgroup = 128 query rows of one head, sweeps key tiles      -> dQ
-//   3. attn_bwd_dkv_kernel: one workgroup = 128 keys of one KV head, sweeps the G query heads
-//                           of its group x 64-row query tiles                                -> dK, dV
+//   3. attn_bwd_dkv2_kernel: one workgroup = 128 keys x ONE query head, sweeps 64-row query tiles -> fp32 partial dK, dV
+//      attn_dkv_reduce_kernel: sums the G per-head partials of a KV group                    -> dK, dV
 // MFMA orientation keeps the softmax row index where the row constants (lse, delta) are cheap:
 //   dq kernel : S^T = K.Q^T, dP^T = V.dO^T (query on the lane), dQ^T += K^T.dS^T with dS^T taken from the accumulator
 //               registers as the B operand and K^T read from the SAME LDS image by ds_read_b64_tr_b16.
@@ -224,174 +224,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnBwdArgs a
 #define DKV_STAGE_BYTES (2 * TILE_BYTES + 512)  // Q tile + dO tile + lse[64] + delta[64]
 #define DKV_LDS_BYTES (2 * DKV_STAGE_BYTES)
 
-__global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const AttnBwdArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nqb = (a.S + BQ - 1) / BQ, nkt = (a.S + BKV - 1) / BKV;
-  const int nqt = (a.S + DKV_QT - 1) / DKV_QT;
-  const int kblk = blockIdx.x;  // 128-key block; low blocks see the most query tiles under a causal mask
-  const int kvh = blockIdx.y, b = blockIdx.z;
-  const int G = a.H / a.KVH;
-  const int r = lane & 31, hh = lane >> 5;
-  const int key = kblk * 128 + wave * 32 + r;  // this lane's key
-  const int krow = min(key, a.S - 1);
-  const int my_kt = 2 * kblk + (wave >> 1);    // 64-key tile index of this wave (for the tile classes)
-
-  // K / V fragments as B operands: X[key = r][d = 16ks + 8hh + j]
-  bf16x8_t kf[8], vf[8];
-  {
-    const bf16_t* kp = a.k + (int64_t)b * a.k_sb + (int64_t)krow * a.k_ss + kvh * HD + 8 * hh;
-    const bf16_t* vp = a.v + (int64_t)b * a.v_sb + (int64_t)krow * a.v_ss + kvh * HD + 8 * hh;
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
-      kf[ks] = *reinterpret_cast<const bf16x8_t*>(kp + 16 * ks);
-      vf[ks] = *reinterpret_cast<const bf16x8_t*>(vp + 16 * ks);
-    }
-  }
-  const int key_doc = a.doc_ids ? a.doc_ids[(int64_t)b * a.S + krow] : 0;
-  const int my_prefix = a.prefix_len ? a.prefix_len[b] : 0;
-
-  // ---- schedule: iteration it = g * nqt + qt over (head of the group, 64-row query tile)
-  const int qt_first = a.flags ? 0 : (kblk * 128) / DKV_QT;  // causal: rows before the block's first key see none of it
-  auto block_class = [&](int qt, int kt) -> int {  // class of (query tile qt, key tile kt)
-    if (a.flags) return a.flags[((int64_t)b * nqb + (qt >> 1)) * nkt + min(kt, nkt - 1)];
-    const int q_lo = qt * DKV_QT, q_hi = q_lo + DKV_QT - 1, k_lo = kt * BKV, k_hi = k_lo + BKV - 1;
-    if (k_lo > q_hi) return 0;
-    return (k_hi <= q_lo) ? 2 : 1;
-  };
-  auto tile_live = [&](int qt) -> bool {
-    return block_class(qt, 2 * kblk) != 0 || (2 * kblk + 1 < nkt && block_class(qt, 2 * kblk + 1) != 0);
-  };
-  const int n_it = G * nqt;
-  auto next_it = [&](int it) {
-    while (it < n_it) {
-      const int qt = it % nqt;
-      if (qt >= qt_first && tile_live(qt)) break;
-      ++it;
-    }
-    return it;
-  };
-
-  const int srow_in = lane >> 4, sslot = lane & 15;
-  auto stage = [&](int buf, int it) {
-    const int g = it / nqt, qt = it % nqt;
-    const int h = kvh * G + g;
-    char* sQ = smem + buf * DKV_STAGE_BYTES;
-    char* sD = sQ + TILE_BYTES;
-    char* sL = sD + TILE_BYTES;
-    const bf16_t* qbase = a.q + (int64_t)b * a.q_sb + h * HD;
-    const bf16_t* dbase = a.d_o + (int64_t)b * a.do_sb + h * HD;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = i * 16 + wave * 4 + srow_in;
-      const int qr = min(qt * DKV_QT + row, a.S - 1);
-      const int c = sslot ^ dual_swz(row);
-      __builtin_amdgcn_global_load_lds((gbl_void*)(qbase + (int64_t)qr * a.q_ss + c * 8), (lds_void*)(sQ + (i * 16 + wave * 4) * 256), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gbl_void*)(dbase + (int64_t)qr * a.do_ss + c * 8), (lds_void*)(sD + (i * 16 + wave * 4) * 256), 16, 0, 0);
-    }
-    if (wave < 2) {  // wave 0: lse[64], wave 1: delta[64]
-      const float* src = (wave == 0 ? a.lse : a.delta) + ((int64_t)b * a.H + h) * a.S + min(qt * DKV_QT + lane, a.S - 1);
-      __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(sL + wave * 256), 4, 0, 0);
-    }
-  };
-
-  f32x16_t dk[4], dv[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) { dk[i][e] = 0.f; dv[i][e] = 0.f; }
-
-  int it = next_it(0);
-  if (it < n_it) stage(0, it);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  int cur = 0;
-  while (it < n_it) {
-    const int itn = next_it(it + 1);
-    if (itn < n_it) stage(cur ^ 1, itn);
-    const int qt = it % nqt;
-    const char* sQ = smem + cur * DKV_STAGE_BYTES;
-    const char* sD = sQ + TILE_BYTES;
-    const float* sL = reinterpret_cast<const float*>(sD + TILE_BYTES);
-    int cls = block_class(qt, my_kt);
-    if (my_kt >= nkt) cls = 0;
-    if (cls == 2 && (qt * DKV_QT + DKV_QT > a.S)) cls = 1;  // rows past the end must be masked out of dK/dV
-    if (cls != 0) {
-#pragma unroll
-      for (int qb32 = 0; qb32 < 2; ++qb32) {
-        f32x16_t st, dp;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) { st[e] = 0.f; dp[e] = 0.f; }
-        const int row = qb32 * 32 + r;
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-          st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(sQ, row, ks, hh), kf[ks], st, 0, 0, 0);
-          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(sD, row, ks, hh), vf[ks], dp, 0, 0, 0);
-        }
-        // accumulator rows are query rows: q_local = qb32*32 + (e&3) + 8(e>>2) + 4hh ; column (lane) = key
-#pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-          const int ql = qb32 * 32 + 8 * g4 + 4 * hh;
-          const f32x4_t l4 = *reinterpret_cast<const f32x4_t*>(sL + ql);
-          const f32x4_t d4 = *reinterpret_cast<const f32x4_t*>(sL + 64 + ql);
-#pragma unroll
-          for (int e2 = 0; e2 < 4; ++e2) {
-            const int e = 4 * g4 + e2;
-            const float lse = (l4[e2] == -INFINITY) ? 0.f : l4[e2];
-            float p = __builtin_amdgcn_exp2f(__builtin_fmaf(st[e], a.scale_log2, -lse));
-            if (cls != 2) {
-              const int qi = qt * DKV_QT + ql + e2;
-              bool ok = (qi < a.S) && (key < a.S) && (key <= qi || key < my_prefix);
-              if (a.doc_ids) ok = ok && (a.doc_ids[(int64_t)b * a.S + min(qi, a.S - 1)] == key_doc);
-              p = ok ? p : 0.f;
-            }
-            st[e] = p;                   // P
-            dp[e] = p * (dp[e] - d4[e2]);  // dS (unscaled)
-          }
-        }
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          bf16x8_t pb, dsb;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) { pb[j] = (__bf16)st[8 * s + j]; dsb[j] = (__bf16)dp[8 * s + j]; }
-#pragma unroll
-          for (int db = 0; db < 4; ++db) {
-            dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(sD, qb32 * 32 + s * 16, db, lane), pb, dv[db], 0, 0, 0);
-            dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(sQ, qb32 * 32 + s * 16, db, lane), dsb, dk[db], 0, 0, 0);
-          }
-        }
-      }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    cur ^= 1;
-    it = itn;
-  }
-
-  if (key < a.S) {
-    bf16_t* kp = a.dk + (int64_t)b * a.dk_sb + (int64_t)key * a.dk_ss + kvh * HD;
-    bf16_t* vp = a.dv + (int64_t)b * a.dv_sb + (int64_t)key * a.dv_ss + kvh * HD;
-#pragma unroll
-    for (int db = 0; db < 4; ++db)
-#pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        u32x2_t pk;
-        pk[0] = pack_bf2(dk[db][4 * g4 + 0] * a.scale, dk[db][4 * g4 + 1] * a.scale);
-        pk[1] = pack_bf2(dk[db][4 * g4 + 2] * a.scale, dk[db][4 * g4 + 3] * a.scale);
-        *reinterpret_cast<u32x2_t*>(kp + 32 * db + 8 * g4 + 4 * hh) = pk;
-        pk[0] = pack_bf2(dv[db][4 * g4 + 0], dv[db][4 * g4 + 1]);
-        pk[1] = pack_bf2(dv[db][4 * g4 + 2], dv[db][4 * g4 + 3]);
-        *reinterpret_cast<u32x2_t*>(vp + 32 * db + 8 * g4 + 4 * hh) = pk;
-      }
-  }
-}
-
-
-// ------------------------------------------------------------------------------------------ dK, dV  (v2)
-// As v1 (a wave owns 32 keys, K/V fragments in registers, dK^T/dV^T in 128 accumulator registers) but one workgroup
-// handles ONE query head of the KV group: 4x the workgroups, heaviest key blocks dispatched first under the causal
-// mask, two workgroups per CU (<= 256 registers) so one wave's softmax VALU overlaps its SIMD partner's MFMAs.
+// One workgroup = 4 waves = 128 keys of ONE query head: a wave owns 32 keys, K/V fragments in registers, dK^T/dV^T in
+// 128 accumulator registers; heaviest key blocks are dispatched first under the causal mask, two workgroups per CU
+// (<= 256 registers) so one wave's softmax VALU overlaps its SIMD partner's MFMAs.
 // The G per-head fp32 partials are summed by attn_dkv_reduce_kernel (deterministic, no atomics).
 #define DKV2_KEYS 128
 
@@ -611,7 +446,7 @@ extern "C" int llx_attn_bwd(const void* q, int64_t q_sb, int64_t q_ss, const voi
     hipError_t e1 = hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, DQ_LDS_BYTES);
     hipError_t e4 = hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, DQ_LDS_BYTES);
     hipError_t e5 = hipFuncSetAttribute((const void*)attn_bwd_dkv2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS_BYTES);
-    hipError_t e2 = hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS_BYTES);
+    hipError_t e2 = hipSuccess;
     hipError_t e3 = hipFuncSetAttribute((const void*)attn_bwd_dkv2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS_BYTES);
     if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess || e5 != hipSuccess) { llx_set_error("llx_attn_bwd: cannot raise LDS limit"); return LLX_ERR_LAUNCH; }
     g_bwd_attr = true;

@@ -225,3 +225,83 @@ def test_audio_prefix_lm_mask(cuda):
     with torch.no_grad():
         loss = model(audio.to(cuda), tokens.to(cuda), labels=labels.to(cuda), block_mask=MaskSpec(prefix_len=torch.tensor([100])))
     assert abs(loss.item() - ref.item()) < 3e-3 * max(1.0, abs(ref.item())), (loss.item(), ref.item())
+
+
+# ------------------------------------------------------------------------------------------------- M3 / N1 / A18
+def test_trainer_accumulation_clip_schedule_and_checkpoint(cuda, tmp_path):
+    """M3 step semantics (accumulate, LR before step, clip) against the oracle loop, then N1: save {step, model, optim},
+    reload into a fresh int8+LoRA model with weights_only=True and continue identically."""
+    from llx.data import LRScheduler
+    from llx.train import Trainer
+
+    p = O.init_params(CFG)
+    p.update(O.init_lora(CFG, 8))
+    pb, pf = bf16_params(p)
+    batches = [_data(1, 256, seed=s) for s in range(4)]
+    train = sorted(k for k in pf if "lora_" in k)
+    ref_losses = O.train_steps({k: v.clone() for k, v in pf.items()}, train, [(t, l, None) for t, l in batches], CFG, lr=1e-3, grad_accum=2,
+                               n_steps=2, warmup=0.5, decay=0.0, clip=1.0)
+    model = build_model(CFG, pb, cuda, lora_rank=8)
+    for n, q in model.named_parameters():
+        q.requires_grad_("lora_" in n)
+    opt = torch.optim.AdamW([q for q in model.parameters() if q.requires_grad], lr=1e-3, weight_decay=0.0)
+    tr = Trainer(model, opt, lr_schedule=LRScheduler(1e-3, 2, 0.5, 0.0), grad_accum=2, clip_grad_norm=1.0)
+    losses = []
+    for s in range(2):
+        mb = [(lambda m, t=t, l=l: m(t.to(cuda), labels=l.to(cuda))) for t, l in batches[2 * s : 2 * s + 2]]
+        losses.append(tr.step(mb).item())
+    for a, b in zip(losses, ref_losses):
+        assert abs(a - b) < 5e-3 * max(1.0, abs(b)), (losses, ref_losses)
+    assert opt.param_groups[0]["lr"] == 1e-3  # step 1 of 2 with warmup 0.5 -> full lr (step 0 ran at lr 0)
+
+    # --- checkpoint round trip with int8 weights (Int8LinearWeight flatten/unflatten + copy_)
+    model8 = build_model(CFG, pb, cuda, lora_rank=8, quantize="int8")
+    opt8 = torch.optim.AdamW([q for n, q in model8.named_parameters() if "lora_" in n], lr=1e-3)
+    for n, q in model8.named_parameters():
+        q.requires_grad_("lora_" in n)
+    t8 = Trainer(model8, opt8)
+    t0, l0 = batches[0]
+    t8.step(lambda m: m(t0.to(cuda), labels=l0.to(cuda)))
+    path = tmp_path / "last.pth"
+    torch.save(t8.state_dict(), path)
+    from subclasses import Int8LinearWeight
+
+    torch.serialization.add_safe_globals([Int8LinearWeight])
+    ckpt = torch.load(path, map_location="cpu", weights_only=True, mmap=True)
+    fresh = build_model(CFG, {k: torch.zeros_like(v) for k, v in pb.items()}, cuda, lora_rank=8, quantize="int8")
+    for n, q in fresh.named_parameters():
+        q.requires_grad_("lora_" in n)
+    optf = torch.optim.AdamW([q for n, q in fresh.named_parameters() if "lora_" in n], lr=1e-3)
+    tf = Trainer(fresh, optf)
+    tf.load_state_dict(ckpt)
+    assert tf.step_idx == 1
+    assert torch.equal(fresh.layers[0].attention.wq.weight.int_data, model8.layers[0].attention.wq.weight.int_data)
+    t1, l1 = batches[1]
+    a = t8.step(lambda m: m(t1.to(cuda), labels=l1.to(cuda)))
+    b = tf.step(lambda m: m(t1.to(cuda), labels=l1.to(cuda)))
+    assert torch.equal(a, b), "resumed run must continue bit-identically (deterministic kernels)"
+    assert torch.equal(fresh.layers[1].feed_forward.w2.lora_b, model8.layers[1].feed_forward.w2.lora_b)
+
+
+def test_dora_linear_standalone(cuda):
+    """A18: DoRALinear.forward (second priority) = fused LoRA GEMM + row-norm rescale; compared with the oracle / golden."""
+    import numpy as np
+    import os
+
+    from modelling import apply_linear_adapter_
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "g08_dora.npz"))
+    lin = torch.nn.Linear(512, 256, bias=True)
+    lin.weight.data.copy_(O.randn("dora_w", (256, 512), 0.05))
+    lin.bias.data.copy_(O.randn("dora_b", (256,), 0.05))
+    lin = lin.bfloat16()
+    apply_linear_adapter_(lin, "dora", rank=8, alpha=16.0)
+    lin.lora_a.data.copy_(O.randn("dora_a", (8, 512), 0.05))
+    lin.lora_b.data.copy_(O.randn("dora_lb", (256, 8), 0.05))
+    lin = lin.to(cuda)
+    x = O.randn("dora_x", (40, 512)).bfloat16()
+    y = lin(x.to(cuda))
+    ref = torch.from_numpy(g["y"])
+    _close(y.float().cpu(), ref, 0.03, "DoRA forward vs reference golden")
+    y.sum().backward()
+    assert lin.m.grad is not None and lin.lora_a.grad is not None and lin.weight.grad is None
