@@ -73,6 +73,14 @@ int llx_attn_bwd(const void* q, int64_t q_sb, int64_t q_ss, const void* k, int64
                  void* dv, int64_t dv_sb, int64_t dv_ss, const int* doc_ids, const int* prefix_len, const void* flags, int64_t B,
                  int64_t S, int64_t H, int64_t KVH, int64_t head_dim, float scale, llx_stream_t s);
 
+/* ---- dense-mask attention forward (inference / KV-cache path): SDPA(q,k,v,mask,is_causal=False,enable_gqa=True) at
+ *      modelling/llama.py:126-127,135-137 with mask = causal_mask[None,None,input_pos] (:194,:205).  q [B,H,Sq,128],
+ *      k/v [B,KVH,Skv,128] (e.g. the KVCache buffers :79-81), mask bool with broadcast strides; forward only. ------- */
+int llx_attn_dense_fwd(const void* q, int64_t q_sb, int64_t q_sh, int64_t q_ss, const void* k, int64_t k_sb, int64_t k_sh, int64_t k_ss,
+                       const void* v, int64_t v_sb, int64_t v_sh, int64_t v_ss, void* o, int64_t o_sb, int64_t o_sh, int64_t o_ss,
+                       const void* mask, int64_t m_sb, int64_t m_sh, int64_t m_sq, int64_t B, int64_t H, int64_t KVH, int64_t Sq, int64_t Skv,
+                       int64_t head_dim, float scale, llx_stream_t s);
+
 /* ---- RoPE: apply_rope at modelling/llama.py:63-73 (in place on the first `nheads` 128-wide heads of each row;
  *      table fp32 [S,64,2] from build_rope :54-60); backward = rotation by -theta. ----------------------------- */
 int llx_rope(const void* x, int64_t x_sb, int64_t x_ss, void* y, int64_t y_sb, int64_t y_ss, const float* table, int64_t B, int64_t S,

@@ -324,6 +324,32 @@ def attn_bwd(q: Tensor, k: Tensor, v: Tensor, o: Tensor, do: Tensor, lse: Tensor
                                 dv.stride(1), L.ptr(d), L.ptr(p), L.ptr(fl), B, S, H, KVH, hd, 1.0 / math.sqrt(hd), L.stream()), "llx_attn_bwd")
 
 
+def attn_dense_fwd(q: Tensor, k: Tensor, v: Tensor, mask: Tensor) -> Tensor:
+    """Inference attention with an explicit bool mask: q [B,H,Sq,128], k/v [B,KVH,Skv,128] (any strides, last dim dense),
+    mask broadcastable to [B,H,Sq,Skv] -> o [B,H,Sq,128].  Forward only."""
+    _chk_bf16(q, k, v)
+    L.require_cuda(mask)
+    B, H, Sq, hd = q.shape
+    KVH, Skv = k.shape[1], k.shape[2]
+    assert mask.dtype is torch.bool and mask.shape[-2:] == (Sq, Skv)
+    for t in (q, k, v):
+        assert t.stride(3) == 1
+    m = mask
+    while m.dim() < 4:
+        m = m.unsqueeze(0)
+    m = m.expand(B if m.shape[0] != 1 else 1, H if m.shape[1] != 1 else 1, Sq, Skv)
+    if m.stride(3) != 1:
+        m = m.contiguous()
+    m_sb = m.stride(0) if m.shape[0] != 1 else 0
+    m_sh = m.stride(1) if m.shape[1] != 1 else 0
+    o = torch.empty(B, H, Sq, hd, device=q.device, dtype=BF16)
+    L.check(_lib().llx_attn_dense_fwd(L.ptr(q), q.stride(0), q.stride(1), q.stride(2), L.ptr(k), k.stride(0), k.stride(1), k.stride(2),
+                                      L.ptr(v), v.stride(0), v.stride(1), v.stride(2), L.ptr(o), o.stride(0), o.stride(1), o.stride(2),
+                                      L.ptr(m), m_sb, m_sh, m.stride(2), B, H, KVH, Sq, Skv, hd, 1.0 / math.sqrt(hd), L.stream()),
+            "llx_attn_dense_fwd")
+    return o
+
+
 # ------------------------------------------------------------------------------------------------- cross entropy
 def ce_fwd_bwd(logits: Tensor, labels: Tensor, write_grad: bool) -> tuple[Tensor, Optional[Tensor]]:
     """Mean CE over labels != -100.  With write_grad the logits buffer is overwritten by d loss / d logits."""

@@ -157,8 +157,8 @@ class Attention(nn.Module):
         self.kv_cache = None
 
     def _run(self, x: Tensor, rope: Tensor, norm: nn.Module | None, residual: bool, mask, input_pos, block_mask) -> Tensor:
-        if self.kv_cache is not None or mask is not None or input_pos is not None:
-            raise LlxError("KV-cache / dense-mask inference attention is not built yet on this platform (training path only)")
+        if self.kv_cache is not None or mask is not None:
+            return self._run_dense(x, rope, norm, residual, mask, input_pos)
         if self.training and self.attn_dropout > 0.0:
             raise LlxError("attention dropout is not supported by the HIP attention kernel (reference default is 0.0)")
         plans = [ops.LinearPlan(m) for m in (self.wq, self.wk, self.wv, self.wo)]
@@ -166,6 +166,34 @@ class Attention(nn.Module):
                                  norm.eps if norm is not None else 0.0, norm is not None, residual)
         tensors = [t for p in plans for t in p.tensors()]
         return ops.AttnBlockFn.apply(x, _rope_f32(rope), norm.weight if norm is not None else None, meta, *tensors)
+
+    def _run_dense(self, x: Tensor, rope: Tensor, norm, residual: bool, mask, input_pos) -> Tensor:
+        """Inference path: KV cache and/or an explicit bool mask (SDPA branch with is_causal=False, llama.py:126-127,135-137).
+        Forward only: training uses block_mask=MaskSpec(...) which has a fused backward."""
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            raise LlxError("dense-mask / KV-cache attention is forward-only here: run it under torch.no_grad() "
+                           "(for training use block_mask=MaskSpec(doc_ids=..., prefix_len=...))")
+        B, L_, _ = x.shape
+        H, KVH, hd = self.num_heads, self.num_kv_heads, self.head_dim
+        xn = norm(x) if norm is not None else x
+        x2 = K._rows2d(xn.contiguous())
+        qkv = torch.empty(B * L_, (H + 2 * KVH) * hd, device=x.device, dtype=x.dtype)
+        ops.LinearPlan(self.wq).forward(x2, out=qkv[:, : H * hd])
+        ops.LinearPlan(self.wk).forward(x2, out=qkv[:, H * hd : (H + KVH) * hd])
+        ops.LinearPlan(self.wv).forward(x2, out=qkv[:, (H + KVH) * hd :])
+        qkv3 = qkv.view(B, L_, -1)
+        K.rope_(qkv3, _rope_f32(rope).contiguous(), H + KVH)
+        q = qkv3[..., : H * hd].unflatten(-1, (H, hd)).transpose(1, 2)
+        k = qkv3[..., H * hd : (H + KVH) * hd].unflatten(-1, (KVH, hd)).transpose(1, 2)
+        v = qkv3[..., (H + KVH) * hd :].unflatten(-1, (KVH, hd)).transpose(1, 2)
+        if self.kv_cache is not None:
+            k, v = self.kv_cache.update(input_pos, k, v)
+        if mask is None:  # no cache, no mask cannot reach here; a cache without mask attends to everything cached
+            mask = torch.ones(L_, k.shape[2], dtype=torch.bool, device=x.device)
+        o = K.attn_dense_fwd(q, k, v, mask)  # [B,H,L,hd]
+        o2 = o.transpose(1, 2).reshape(B * L_, H * hd)
+        y, _ = ops.LinearPlan(self.wo).forward(o2, residual=K._rows2d(x.contiguous()) if residual else None)
+        return y.view(B, L_, -1)
 
     def forward(self, x: Tensor, rope: Tensor, *, mask: Tensor | None = None, input_pos: Tensor | None = None,
                 block_mask=None) -> Tensor:

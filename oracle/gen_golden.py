@@ -330,6 +330,25 @@ if mel_filter_bank is not None:
 else:
     print("transformers.audio_utils not importable: mel cross-check skipped")
 
+# ------------------------------------------------------------------------------------------------- G14 KV-cache inference
+mi = ref_model(params)
+mi.build_cache(inference=True)
+mi.eval()
+tok_i, _ = tokens_labels(1, 96)
+cache = O.new_cache(CFG)
+with torch.no_grad():
+    pre_ref = mi(tok_i[:, :64], input_pos=torch.arange(64))
+    pre_or = O.llama_forward_cached(tok_i[:, :64], params, CFG, cache, torch.arange(64))
+    close(pre_or, pre_ref, 2e-5, "kv-cache prefill")
+    close(pre_ref, logits_ref.new_tensor(O.llama_forward(tok_i[:, :64], params, CFG)), 2e-5, "prefill == causal forward")
+    dec = []
+    for t in range(64, 68):
+        d_ref = mi(tok_i[:, t : t + 1], input_pos=torch.tensor([t]))
+        d_or = O.llama_forward_cached(tok_i[:, t : t + 1], params, CFG, cache, torch.tensor([t]))
+        close(d_or, d_ref, 2e-5, f"kv-cache decode {t}")
+        dec.append(d_ref[:, 0, ::8])
+save("g14_kv_cache", prefill_slice=pre_ref[:, ::8, ::8], decode_slices=torch.stack(dec))
+
 # ------------------------------------------------------------------------------------------------- G13 3-step trajectory
 lp = O.init_lora(CFG, 8)
 m = ref_model(params)

@@ -286,6 +286,40 @@ def llama_forward(tokens: Tensor, p: dict, cfg: Cfg, *, mask: Optional[Tensor] =
     return x
 
 
+def llama_forward_cached(tokens: Tensor, p: dict, cfg: Cfg, cache: dict, input_pos: Tensor) -> Tensor:
+    """Inference path of Llama.forward with KV caches (modelling/llama.py:83-90,126-127,135-137,189-194,205-207).
+
+    ``cache[i] = (k_cache, v_cache)`` of shape [1, KVH, max_seq_len, hd] (zeros initially), updated in place at
+    ``input_pos``; the mask is ``tril[input_pos]`` over the WHOLE cache length.  Reference quirk reproduced: the RoPE rows are
+    ``rope[:L]`` of the current call (:207), i.e. positions restart at 0 for every call regardless of ``input_pos``."""
+    L = tokens.shape[1]
+    x = F.embedding(tokens, p["tok_embeddings.weight"])
+    table = rope_table(cfg)[:L]
+    mask = torch.tril(torch.ones(cfg.max_seq_len, cfg.max_seq_len, dtype=torch.bool))[None, None, input_pos]
+    for i in range(cfg.num_layers):
+        pre = f"layers.{i}."
+        h = rmsnorm(x, p[pre + "attention_norm.weight"])
+        B = h.shape[0]
+        q = linear(h, p, pre + "attention.wq").view(B, L, cfg.num_heads, cfg.head_dim)
+        k = linear(h, p, pre + "attention.wk").view(B, L, cfg.num_kv_heads, cfg.head_dim)
+        v = linear(h, p, pre + "attention.wv").view(B, L, cfg.num_kv_heads, cfg.head_dim)
+        q = rope_apply(q, table).transpose(1, 2)
+        k = rope_apply(k, table).transpose(1, 2)
+        v = v.transpose(1, 2)
+        kc, vc = cache[i]
+        kc[:, :, input_pos] = k
+        vc[:, :, input_pos] = v
+        o = sdpa(q, kc, vc, mask).transpose(1, 2).reshape(B, L, -1)
+        x = x + linear(o, p, pre + "attention.wo")
+        x = x + feed_forward(rmsnorm(x, p[pre + "ffn_norm.weight"]), p, pre + "feed_forward.")
+    return F.linear(rmsnorm(x, p["norm.weight"]), p["output.weight"])
+
+
+def new_cache(cfg: Cfg, dtype=torch.float32) -> dict:
+    shape = (1, cfg.num_kv_heads, cfg.max_seq_len, cfg.head_dim)
+    return {i: (torch.zeros(shape, dtype=dtype), torch.zeros(shape, dtype=dtype)) for i in range(cfg.num_layers)}
+
+
 # --------------------------------------------------------------------------------------------------
 # LoRA / DoRA  (modelling/lora.py:19-62)
 # --------------------------------------------------------------------------------------------------

@@ -305,3 +305,42 @@ def test_dora_linear_standalone(cuda):
     _close(y.float().cpu(), ref, 0.03, "DoRA forward vs reference golden")
     y.sum().backward()
     assert lin.m.grad is not None and lin.lora_a.grad is not None and lin.weight.grad is None
+
+
+def test_kv_cache_prefill_and_decode(cuda):
+    """N2 / A5 / M5: build_cache(inference=True); prefill with input_pos then single-token decode steps follow the oracle's
+    restatement of the reference's cached path (KVCache.update + causal_mask[None, None, input_pos], modelling/llama.py:83-90,
+    189-194,205-207 - including its quirk that RoPE rows restart at 0 on every call; pinned by fixture g14_kv_cache)."""
+    pb, pf = bf16_params(O.init_params(CFG))
+    tokens, _ = _data(1, 96)
+    from tests.util import to_model_config
+    from modelling import Llama
+
+    model = Llama(to_model_config(CFG)).bfloat16()
+    model.load_state_dict(pb, strict=False)
+    model.build_cache(inference=True)
+    model = model.to(cuda).eval()
+    assert model.causal_mask.shape == (CFG.max_seq_len, CFG.max_seq_len) and model.layers[0].attention.kv_cache.k_cache.shape == (1, 1, CFG.max_seq_len, 128)
+    cache = O.new_cache(CFG)
+    with torch.no_grad():
+        pre = model(tokens[:, :64].to(cuda), input_pos=torch.arange(64, device=cuda))
+        ref = O.llama_forward_cached(tokens[:, :64], pf, CFG, cache, torch.arange(64))
+        _close(pre.float().cpu(), ref, 0.03, "prefill logits")
+        _close(pre.float().cpu(), O.llama_forward(tokens[:, :64], pf, CFG), 0.03, "prefill == causal forward")
+        for t in range(64, 70):
+            step = model(tokens[:, t : t + 1].to(cuda), input_pos=torch.tensor([t], device=cuda))
+            want = O.llama_forward_cached(tokens[:, t : t + 1], pf, CFG, cache, torch.tensor([t]))
+            _close(step.float().cpu(), want, 0.03, f"decode logits at {t}")
+    # dense bool mask= on a layer (the reference's small-shape prefix-LM route), forward only
+    layer = model.layers[0]
+    layer.attention.kv_cache = None
+    hid = O.randn("hidden1", (1, 384, 512), 0.5).bfloat16()
+    dense = O.prefix_lm_mask(384, [128])
+    with torch.no_grad():
+        out = layer(hid.to(cuda), model.rope[:384], mask=dense.to(cuda))
+    want = O.layer(hid.float(), pf, 0, CFG, O.rope_table(CFG)[:384], dense)
+    _close(out.float().cpu(), want, 0.03, "layer with dense prefix-LM mask")
+    from llx._lib import LlxError
+
+    with pytest.raises(LlxError):
+        layer(hid.to(cuda).requires_grad_(), model.rope[:384], mask=dense.to(cuda))

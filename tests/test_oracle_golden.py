@@ -174,3 +174,16 @@ def test_three_step_trajectory():
     batches = [(*tokens_labels(1, 256, seed=s), None) for s in range(3)]
     losses = O.train_steps(params, sorted(lp), batches, CFG, lr=1e-3)
     np.testing.assert_allclose(losses, g["losses"].numpy(), atol=2e-5)
+
+
+def test_kv_cache_path():
+    g = G("g14_kv_cache")
+    params = O.init_params(CFG)
+    tok, _ = tokens_labels(1, 96)
+    cache = O.new_cache(CFG)
+    pre = O.llama_forward_cached(tok[:, :64], params, CFG, cache, torch.arange(64))
+    torch.testing.assert_close(pre[:, ::8, ::8], g["prefill_slice"], atol=2e-5, rtol=1e-4)
+    torch.testing.assert_close(pre, O.llama_forward(tok[:, :64], params, CFG), atol=2e-5, rtol=1e-4)  # prefill == causal forward
+    for i, t in enumerate(range(64, 68)):
+        d = O.llama_forward_cached(tok[:, t : t + 1], params, CFG, cache, torch.tensor([t]))
+        torch.testing.assert_close(d[:, 0, ::8], g["decode_slices"][i], atol=2e-5, rtol=1e-4)
