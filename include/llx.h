@@ -111,6 +111,8 @@ int64_t llx_skinny_tn_workspace_bytes(int64_t M, int64_t N, int64_t R);
 int llx_skinny_tn(const void* U, const void* Y, int64_t ldy, void* out, int64_t out_ld, int64_t M, int64_t N, int64_t R, float scale,
                   int transpose_out, int accumulate, void* workspace, llx_stream_t s);
 int llx_pad64(const void* in, int64_t ld, void* out, int64_t R, int64_t C, float scale, int transpose, llx_stream_t s);
+int llx_lora_pack(const void* in, int64_t ld, void* out, int64_t out_ld, int64_t R, int64_t C, int64_t row_off, int64_t col_off, float scale,
+                  int transpose, llx_stream_t s);   /* batched LoRA operand images of a linear group (q|k|v, gate|up) */
 
 /* ---- audio front end (modelling/audio.py:26-36,53-60): MelSpectrogram(n_fft 512, win 400, hop 160, 128 slaney mels,
  *      power 2, centre/reflect) -> log10/clip/CMN -> bf16 time-major padded features; exact-erf GELU; conv k=3 helpers.

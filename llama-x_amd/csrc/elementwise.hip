@@ -297,3 +297,26 @@ extern "C" int llx_pad64(const void* in, int64_t ld, void* out, int64_t R, int64
   LLX_LAUNCH_CHECK("llx_pad64");
   return LLX_OK;
 }
+
+// Scatter a small [R, C] bf16 matrix (scaled) into a bigger zero-initialised operand image:
+//   transpose = 0: out[(row_off + r) * out_ld + col_off + c] = scale * in[r, c]
+//   transpose = 1: out[(row_off + c) * out_ld + col_off + r] = scale * in[r, c]
+// Builds the batched LoRA operands of a linear group (block-diagonal s*B, s*A^T, B^T, stacked A).
+__global__ void lora_pack_kernel(const bf16_t* __restrict__ in, int64_t ld, bf16_t* __restrict__ out, int64_t out_ld, int R, int C, int row_off,
+                                 int col_off, float scale, int transpose) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)R * C) return;
+  const int r = (int)(idx / C), c = (int)(idx % C);
+  const float v = bf2f(in[(int64_t)r * ld + c]) * scale;
+  if (transpose) out[(int64_t)(row_off + c) * out_ld + col_off + r] = f2bf(v);
+  else out[(int64_t)(row_off + r) * out_ld + col_off + c] = f2bf(v);
+}
+
+extern "C" int llx_lora_pack(const void* in, int64_t ld, void* out, int64_t out_ld, int64_t R, int64_t C, int64_t row_off, int64_t col_off,
+                             float scale, int transpose, hipStream_t stream) {
+  LLX_REQUIRE(in && out && R > 0 && C > 0, "llx_lora_pack: bad arguments");
+  hipLaunchKernelGGL(lora_pack_kernel, dim3((unsigned)cdiv64(R * C, 256)), dim3(256), 0, stream, (const bf16_t*)in, ld, (bf16_t*)out, out_ld, (int)R,
+                     (int)C, (int)row_off, (int)col_off, scale, transpose);
+  LLX_LAUNCH_CHECK("llx_lora_pack");
+  return LLX_OK;
+}

@@ -49,6 +49,7 @@ SIGNATURES: dict[str, tuple] = {
     "llx_gelu_bwd": (c_int, [_P, _L, _P, _L, _P, _L, _L, _L, _P]),
     "llx_col2im3": (c_int, [_P, _P, _L, _L, _L, _L, _P]),
     "llx_conv_w_reorder": (c_int, [_P, _P, _L, _L, _I, _P]),
+    "llx_lora_pack": (c_int, [_P, _L, _P, _L, _L, _L, _L, _L, _F, _I, _P]),
     "llx_pad64": (c_int, [_P, _L, _P, _L, _L, _F, _I, _P]),
     "llx_ce_workspace_bytes": (c_int64, [_L]),
     "llx_ce_fwd_bwd": (c_int, [_P, _L, _P, _L, _P, _P, _P, _L, _L, _P]),

@@ -124,6 +124,17 @@ def pad64(x: Tensor, scale_: float = 1.0, transposed: bool = False) -> Tensor:
     return out
 
 
+def lora_pack(x: Tensor, out: Tensor, row_off: int, col_off: int, scale_: float = 1.0, transposed: bool = False) -> None:
+    """Scatter scale*x (or its transpose) into ``out`` at (row_off, col_off); ``out`` is a pre-zeroed operand image."""
+    _chk_bf16(x, out)
+    assert x.dim() == 2 and x.stride(1) == 1 and out.dim() == 2 and out.stride(1) == 1
+    R, C = x.shape
+    rr, cc = (C, R) if transposed else (R, C)
+    assert row_off + rr <= out.shape[0] and col_off + cc <= out.shape[1], (x.shape, out.shape, row_off, col_off, transposed)
+    L.check(_lib().llx_lora_pack(L.ptr(x), x.stride(0), L.ptr(out), out.stride(0), R, C, row_off, col_off, scale_, int(transposed), L.stream()),
+            "llx_lora_pack")
+
+
 def gemm_tn(a: Tensor, b: Tensor) -> Tensor:
     """a[M,N1]^T @ b[M,N2] -> [N1,N2] (weight gradients): transposed, zero-padded copies feed the NT kernel."""
     at, bt = transpose(a, 64), transpose(b, 64)

@@ -158,6 +158,148 @@ class LinearPlan:
         return dx, grads
 
 
+def _cached_multi(tensors: Sequence[Tensor], tag: str, build):
+    """Cache on the first tensor, keyed by the version counters (and devices) of all of them."""
+    store = tensors[0].__dict__.setdefault("_llx_cache", {})
+    key = tuple((t._version, str(t.device)) for t in tensors)
+    hit = store.get(tag)
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    val = build()
+    store[tag] = (key, val)
+    return val
+
+
+class GroupPlan:
+    """Linears that read the SAME input (wq|wk|wv, w1|w3), executed as one GEMM over concatenated weight images.
+
+    Forward: y[M, sum N] = x @ [W_0; W_1; ...]^T with the members' LoRA adapters batched into one skinny product
+    (t = x @ [A_0; A_1; ...]^T, 64 columns) and one block-diagonal K-extension operand; backward: one dgrad GEMM over the
+    concatenated transposed image (K = sum N) and one skinny product per adapter factor.  Better tile quantisation
+    (1792 tiles = 7 full waves for gate|up instead of 2 x 3.5), a third of the launches, x / dy read once.
+    Falls back to per-member plans when the members cannot be fused (mixed kinds, biases, sum of ranks > 64)."""
+
+    def __init__(self, mods: Sequence[nn.Linear]):
+        self.members = [LinearPlan(m) for m in mods]
+        m0 = self.members[0]
+        self.K = m0.K
+        self.Ns = [m.N for m in self.members]
+        self.N = sum(self.Ns)
+        self.n_off = [sum(self.Ns[:i]) for i in range(len(self.Ns))]
+        self.ranks = [m.rank for m in self.members]
+        self.R = sum(self.ranks)
+        self.r_off = [sum(self.ranks[:i]) for i in range(len(self.ranks))]
+        same_kind = all((m.int8, m.dynamic) == (m0.int8, m0.dynamic) for m in self.members)
+        same_scale = len({m.scale for m in self.members if m.rank > 0}) <= 1
+        lora_all_or_none = all(r > 0 for r in self.ranks) or self.R == 0
+        self.fused = (same_kind and same_scale and lora_all_or_none and self.R <= 64 and all(m.bias is None for m in self.members)
+                      and all(m.K == self.K for m in self.members))
+        self.int8, self.dynamic = m0.int8, m0.dynamic
+        self.scale = next((m.scale for m in self.members if m.rank > 0), 1.0)
+
+    def tensors(self) -> list[Tensor]:
+        return [t for m in self.members for t in m.tensors()]
+
+    # ---- cached concatenated images of the (normally frozen) base weights
+    def _weights(self):
+        return [(m.weight.int_data if m.int8 else m.weight) for m in self.members]
+
+    def w_cat(self) -> Tensor:
+        ws = self._weights()
+        if self.int8 and self.dynamic:
+            return _cached_multi(ws, "cat_i8", lambda: torch.cat([w.detach() for w in ws], 0))
+        if self.int8:
+            return _cached_multi(ws, "cat_bf16", lambda: K.i8_to_bf16(torch.cat([w.detach() for w in ws], 0)))
+        return _cached_multi(ws, "cat", lambda: torch.cat([w.detach() for w in ws], 0) if len(ws) > 1 else ws[0].detach())
+
+    def wt_cat(self) -> Tensor:
+        ws = self._weights()
+        return _cached_multi(ws, "cat_t", lambda: K.transpose(torch.cat([w.detach() for w in ws], 0) if len(ws) > 1 else ws[0].detach()))
+
+    def scale_cat(self) -> Tensor:
+        ss = [m.weight.scale for m in self.members]
+        return _cached_multi(ss, "cat_scale", lambda: torch.cat(ss, 0) if len(ss) > 1 else ss[0])
+
+    # ---- forward
+    def forward(self, x: Tensor, out: Tensor):
+        """out: [M, sum N] (row-strided view allowed).  Returns the saved LoRA intermediate t (or a per-member list)."""
+        if not self.fused:
+            return [m.forward(x, out=out[:, o : o + n])[1] for m, o, n in zip(self.members, self.n_off, self.Ns)]
+        t = b2 = None
+        if self.R > 0:
+            a_cat = torch.empty(self.R, self.K, device=x.device, dtype=BF16)
+            b2 = torch.zeros(self.N, K.SK_PAD, device=x.device, dtype=BF16)
+            for m, ro, no in zip(self.members, self.r_off, self.n_off):
+                K.lora_pack(m.lora_a.detach(), a_cat, ro, 0)
+                K.lora_pack(m.lora_b.detach(), b2, no, ro, self.scale)
+            t = K.skinny_nt(x, a_cat)
+        if not self.int8:
+            K.gemm_nt(x, self.w_cat(), out=out, a2=t, b2=b2)
+            return t
+        if self.dynamic:
+            from subclasses.int8 import quantize_int8_rowwise
+            from subclasses.int8_mm import _launch as i8_gemm
+
+            xi, xs = quantize_int8_rowwise(x)
+            y0 = i8_gemm(xi, self.w_cat(), xs, self.scale_cat(), out=out if self.R == 0 else None)
+        else:
+            y0 = K.gemm_nt(x, self.w_cat(), out=out if self.R == 0 else None, epilogue=K.EPI_COLSCALE, e=self.scale_cat())
+        if self.R > 0:
+            K.gemm_nt(t, b2, out=out, epilogue=K.EPI_RESIDUAL, e=y0)
+        return t
+
+    # ---- backward: returns (dx, grads aligned with tensors())
+    def backward(self, dy: Tensor, x: Tensor, saved, needs: Sequence[bool], need_dx: bool, dx_out: Optional[Tensor] = None):
+        if not self.fused:
+            grads, dx, first = [], None, True
+            ni = 0
+            for m, o, n, t in zip(self.members, self.n_off, self.Ns, saved):
+                cnt = len(m.tensors())
+                d, g = m.backward(dy[:, o : o + n], x, t, needs[ni : ni + cnt], need_dx, dx_out, not first)
+                ni += cnt
+                grads += g
+                dx = d if d is not None else dx
+                first = False
+            return dx, grads
+        t = saved
+        u = gA = gBt = None
+        ni = iter(needs)
+        need = []
+        for m in self.members:
+            cnt = len(m.tensors())
+            need.append([next(ni) for _ in range(cnt)])
+        if self.R > 0:
+            bT = torch.zeros(self.R, self.N, device=dy.device, dtype=BF16)
+            for m, ro, no in zip(self.members, self.r_off, self.n_off):
+                K.lora_pack(m.lora_b.detach(), bT, ro, no, 1.0, transposed=True)
+            u = K.skinny_nt(dy, bT)  # [M,64]: column block i = dy_i @ B_i
+            if any(nd[-2] for nd in need):
+                gA = torch.empty(self.R, self.K, device=dy.device, dtype=BF16)
+                K.skinny_tn(u, x, self.R, self.scale, gA, transpose_out=False)
+            if any(nd[-1] for nd in need):
+                gBt = torch.empty(self.N, self.R, device=dy.device, dtype=BF16)
+                K.skinny_tn(t, dy, self.R, self.scale, gBt, transpose_out=True)
+        grads: list[Optional[Tensor]] = []
+        for m, nd, ro, no, n in zip(self.members, need, self.r_off, self.n_off, self.Ns):
+            j = 0
+            if not m.int8:
+                grads.append(K.gemm_tn(dy[:, no : no + n], x) if nd[j] else None)
+                j += 1
+            if m.rank > 0:
+                grads.append(gA[ro : ro + m.rank] if nd[j] else None)
+                grads.append(gBt[no : no + n, ro : ro + m.rank].contiguous() if nd[j + 1] else None)
+        dx = None
+        if need_dx:
+            b2 = None
+            if self.R > 0:
+                b2 = torch.zeros(self.K, K.SK_PAD, device=dy.device, dtype=BF16)
+                for m, ro in zip(self.members, self.r_off):
+                    K.lora_pack(m.lora_a.detach(), b2, 0, ro, self.scale, transposed=True)
+            g = K.scale(dy, colscale=self.scale_cat()) if self.int8 else dy  # (g * scale) rounded (subclasses/int8.py:127)
+            dx = K.gemm_nt(g, self.wt_cat(), out=dx_out, a2=u, b2=b2)
+        return dx, grads
+
+
 def _plans_tensors(plans: Sequence[LinearPlan]) -> tuple[list[Tensor], list[int]]:
     ts, counts = [], []
     for p in plans:
@@ -237,8 +379,8 @@ def rmsnorm(x: Tensor, w: Tensor, eps: float) -> Tensor:
 # attention residual branch:  [x +] wo( attn( rope(wq xn), rope(wk xn), wv xn ) ),  xn = [rmsnorm(x)]
 # =================================================================================================
 class AttnBlockMeta:
-    def __init__(self, plans, num_heads, num_kv_heads, head_dim, mask, eps, fuse_norm, fuse_residual):
-        self.wq, self.wk, self.wv, self.wo = plans
+    def __init__(self, qkv: GroupPlan, wo: LinearPlan, num_heads, num_kv_heads, head_dim, mask, eps, fuse_norm, fuse_residual):
+        self.qkv, self.wo = qkv, wo
         self.H, self.KVH, self.hd = num_heads, num_kv_heads, head_dim
         self.mask, self.eps = mask, eps
         self.fuse_norm, self.fuse_residual = fuse_norm, fuse_residual
@@ -257,9 +399,7 @@ class AttnBlockFn(Function):
             xn, rstd = x2, None
         W = (H + 2 * KVH) * hd
         qkv = torch.empty(B * S, W, device=x.device, dtype=BF16)
-        _, tq = meta.wq.forward(xn, out=qkv[:, : H * hd])
-        _, tk = meta.wk.forward(xn, out=qkv[:, H * hd : (H + KVH) * hd])
-        _, tv = meta.wv.forward(xn, out=qkv[:, (H + KVH) * hd :])
+        tqkv = meta.qkv.forward(xn, qkv)
         qkv3 = qkv.view(B, S, W)
         K.rope_(qkv3, rope, H + KVH)
         q = qkv3[..., : H * hd].unflatten(-1, (H, hd))
@@ -270,20 +410,20 @@ class AttnBlockFn(Function):
         y, to = meta.wo.forward(o2, residual=x2 if meta.fuse_residual else None)
         ctx.meta = meta
         ctx.save_for_backward(x, rope, norm_w)
-        ctx.saved = (x2, xn, rstd, qkv3, o, lse, tq, tk, tv, to)
+        ctx.saved = (x2, xn, rstd, qkv3, o, lse, tqkv, to)
         return y.view(B, S, D)
 
     @staticmethod
     def backward(ctx, dy: Tensor):
         meta: AttnBlockMeta = ctx.meta
         x, rope, norm_w = ctx.saved_tensors
-        x2, xn, rstd, qkv3, o, lse, tq, tk, tv, to = ctx.saved
+        x2, xn, rstd, qkv3, o, lse, tqkv, to = ctx.saved
         B, S, D = x.shape
         H, KVH, hd = meta.H, meta.KVH, meta.hd
         dy2 = K._rows2d(dy.contiguous())
         needs = list(ctx.needs_input_grad[4:])
-        counts = [len(p.tensors()) for p in (meta.wq, meta.wk, meta.wv, meta.wo)]
-        nq, nk, nv, no = (needs[sum(counts[:i]) : sum(counts[: i + 1])] for i in range(4))
+        n_qkv = len(meta.qkv.tensors())
+        nqkv, no = needs[:n_qkv], needs[n_qkv:]
         # wo
         do2, g_o = meta.wo.backward(dy2, o.view(B * S, H * hd), to, no)
         # attention
@@ -301,9 +441,7 @@ class AttnBlockFn(Function):
         need_dx = ctx.needs_input_grad[0]
         need_dxn = need_dx or (meta.fuse_norm and ctx.needs_input_grad[2])  # the norm weight gradient needs d(xn) too
         dxn = torch.empty(B * S, D, device=x.device, dtype=BF16) if need_dxn else None
-        _, g_q = meta.wq.backward(d2[:, : H * hd], xn, tq, nq, need_dxn, dxn, False)
-        _, g_k = meta.wk.backward(d2[:, H * hd : (H + KVH) * hd], xn, tk, nk, need_dxn, dxn, True)
-        _, g_v = meta.wv.backward(d2[:, (H + KVH) * hd :], xn, tv, nv, need_dxn, dxn, True)
+        _, g_qkv = meta.qkv.backward(d2, xn, tqkv, nqkv, need_dxn, dxn)
         dx = dnw = None
         if meta.fuse_norm:
             if need_dxn:
@@ -312,15 +450,15 @@ class AttnBlockFn(Function):
             dx = dxn
         if need_dx and meta.fuse_residual:
             dx = K.add(dx, dy2)
-        return (dx.view(B, S, D) if (dx is not None and need_dx) else None, None, dnw, None, *g_q, *g_k, *g_v, *g_o)
+        return (dx.view(B, S, D) if (dx is not None and need_dx) else None, None, dnw, None, *g_qkv, *g_o)
 
 
 # =================================================================================================
 # MLP residual branch:  [x +] w2( silu(w1 xn) * w3 xn ),  xn = [rmsnorm(x)]
 # =================================================================================================
 class MLPBlockMeta:
-    def __init__(self, plans, eps, fuse_norm, fuse_residual):
-        self.w1, self.w3, self.w2 = plans
+    def __init__(self, w13: GroupPlan, w2: LinearPlan, eps, fuse_norm, fuse_residual):
+        self.w13, self.w2 = w13, w2
         self.eps, self.fuse_norm, self.fuse_residual = eps, fuse_norm, fuse_residual
 
 
@@ -334,35 +472,33 @@ class MLPBlockFn(Function):
             xn, rstd = K.rmsnorm_fwd(x2, norm_w.detach(), meta.eps)
         else:
             xn, rstd = x2, None
-        T, I = x2.shape[0], meta.w1.N
+        T, I = x2.shape[0], meta.w13.Ns[0]
         gu = torch.empty(T, 2 * I, device=x.device, dtype=BF16)
-        _, t1 = meta.w1.forward(xn, out=gu[:, :I])
-        _, t3 = meta.w3.forward(xn, out=gu[:, I:])
+        t13 = meta.w13.forward(xn, gu)
         h = K.swiglu_fwd(gu[:, :I], gu[:, I:])
         y, t2 = meta.w2.forward(h, residual=x2 if meta.fuse_residual else None)
         ctx.meta = meta
         ctx.save_for_backward(x, norm_w)
-        ctx.saved = (x2, xn, rstd, gu, h, t1, t3, t2)
+        ctx.saved = (x2, xn, rstd, gu, h, t13, t2)
         return y.view(shape)
 
     @staticmethod
     def backward(ctx, dy: Tensor):
         meta: MLPBlockMeta = ctx.meta
         x, norm_w = ctx.saved_tensors
-        x2, xn, rstd, gu, h, t1, t3, t2 = ctx.saved
-        T, I = x2.shape[0], meta.w1.N
+        x2, xn, rstd, gu, h, t13, t2 = ctx.saved
+        T, I = x2.shape[0], meta.w13.Ns[0]
         dy2 = K._rows2d(dy.contiguous())
         needs = list(ctx.needs_input_grad[3:])
-        counts = [len(p.tensors()) for p in (meta.w1, meta.w3, meta.w2)]
-        n1, n3, n2 = (needs[sum(counts[:i]) : sum(counts[: i + 1])] for i in range(3))
+        n_13 = len(meta.w13.tensors())
+        n13, n2 = needs[:n_13], needs[n_13:]
         dh, g_2 = meta.w2.backward(dy2, h, t2, n2)
         dgu = torch.empty(T, 2 * I, device=x.device, dtype=BF16)
         K.swiglu_bwd(dh, gu[:, :I], gu[:, I:], dgu[:, :I], dgu[:, I:])
         need_dx = ctx.needs_input_grad[0]
         need_dxn = need_dx or (meta.fuse_norm and ctx.needs_input_grad[1])
         dxn = torch.empty_like(x2) if need_dxn else None
-        _, g_1 = meta.w1.backward(dgu[:, :I], xn, t1, n1, need_dxn, dxn, False)
-        _, g_3 = meta.w3.backward(dgu[:, I:], xn, t3, n3, need_dxn, dxn, True)
+        _, g_13 = meta.w13.backward(dgu, xn, t13, n13, need_dxn, dxn)
         dx = dnw = None
         if meta.fuse_norm:
             if need_dxn:
@@ -371,7 +507,7 @@ class MLPBlockFn(Function):
             dx = dxn
         if need_dx and meta.fuse_residual:
             dx = K.add(dx, dy2)
-        return (dx.view(x.shape) if (dx is not None and need_dx) else None, dnw, None, *g_1, *g_3, *g_2)
+        return (dx.view(x.shape) if (dx is not None and need_dx) else None, dnw, None, *g_13, *g_2)
 
 
 # =================================================================================================

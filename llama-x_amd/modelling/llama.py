@@ -161,10 +161,10 @@ class Attention(nn.Module):
             return self._run_dense(x, rope, norm, residual, mask, input_pos)
         if self.training and self.attn_dropout > 0.0:
             raise LlxError("attention dropout is not supported by the HIP attention kernel (reference default is 0.0)")
-        plans = [ops.LinearPlan(m) for m in (self.wq, self.wk, self.wv, self.wo)]
-        meta = ops.AttnBlockMeta(plans, self.num_heads, self.num_kv_heads, self.head_dim, _as_maskspec(block_mask),
+        qkv, wo = ops.GroupPlan((self.wq, self.wk, self.wv)), ops.LinearPlan(self.wo)
+        meta = ops.AttnBlockMeta(qkv, wo, self.num_heads, self.num_kv_heads, self.head_dim, _as_maskspec(block_mask),
                                  norm.eps if norm is not None else 0.0, norm is not None, residual)
-        tensors = [t for p in plans for t in p.tensors()]
+        tensors = qkv.tensors() + wo.tensors()
         return ops.AttnBlockFn.apply(x, _rope_f32(rope), norm.weight if norm is not None else None, meta, *tensors)
 
     def _run_dense(self, x: Tensor, rope: Tensor, norm, residual: bool, mask, input_pos) -> Tensor:
@@ -178,9 +178,7 @@ class Attention(nn.Module):
         xn = norm(x) if norm is not None else x
         x2 = K._rows2d(xn.contiguous())
         qkv = torch.empty(B * L_, (H + 2 * KVH) * hd, device=x.device, dtype=x.dtype)
-        ops.LinearPlan(self.wq).forward(x2, out=qkv[:, : H * hd])
-        ops.LinearPlan(self.wk).forward(x2, out=qkv[:, H * hd : (H + KVH) * hd])
-        ops.LinearPlan(self.wv).forward(x2, out=qkv[:, (H + KVH) * hd :])
+        ops.GroupPlan((self.wq, self.wk, self.wv)).forward(x2, qkv)
         qkv3 = qkv.view(B, L_, -1)
         K.rope_(qkv3, _rope_f32(rope).contiguous(), H + KVH)
         q = qkv3[..., : H * hd].unflatten(-1, (H, hd)).transpose(1, 2)
@@ -209,9 +207,9 @@ class FeedForward(nn.Module):
         self.act = nn.SiLU()
 
     def _run(self, x: Tensor, norm: nn.Module | None, residual: bool) -> Tensor:
-        plans = [ops.LinearPlan(m) for m in (self.w1, self.w3, self.w2)]
-        meta = ops.MLPBlockMeta(plans, norm.eps if norm is not None else 0.0, norm is not None, residual)
-        tensors = [t for p in plans for t in p.tensors()]
+        w13, w2 = ops.GroupPlan((self.w1, self.w3)), ops.LinearPlan(self.w2)
+        meta = ops.MLPBlockMeta(w13, w2, norm.eps if norm is not None else 0.0, norm is not None, residual)
+        tensors = w13.tensors() + w2.tensors()
         return ops.MLPBlockFn.apply(x, norm.weight if norm is not None else None, meta, *tensors)
 
     def forward(self, x: Tensor) -> Tensor:
