@@ -109,12 +109,13 @@ def cpu_baseline(seq: int, rank: int):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--seq", type=int, default=4096)
     ap.add_argument("--rank", type=int, default=16)
     ap.add_argument("--model", default="llama31_8b", choices=["llama31_8b", "tiny"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a captured hipGraph (single GPU)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -135,7 +136,8 @@ def main():
     model, cfg = build_model(args.model, args.seq, args.rank, device)
     trainable = [p for p in model.parameters() if p.requires_grad]
     buckets = GradBuckets(model, n_buckets=4)
-    optim = torch.optim.AdamW(trainable, lr=1e-4, weight_decay=0.0, fused=True)
+    use_graph = world == 1 and not args.no_graph
+    optim = torch.optim.AdamW(trainable, lr=1e-4, weight_decay=0.0, fused=True, capturable=use_graph)
 
     S = args.seq
     gen = torch.Generator(device=device)
@@ -147,7 +149,7 @@ def main():
         labels[:, -1] = -100
         return ids, labels
 
-    def step():
+    def eager_step():
         ids, labels = batch()
         loss = model(ids, labels=labels)
         loss.backward()
@@ -155,6 +157,33 @@ def main():
         optim.step()
         buckets.zero_grad()
         return loss
+
+    step = eager_step
+    if use_graph:
+        # The step has static shapes and no host decisions: capture forward + backward + AdamW once into a hipGraph and
+        # replay it, so that ~3000 kernel launches cost one host call (the batch is copied into static input buffers).
+        ids_buf, labels_buf = batch()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):  # warm caches (transposed / concatenated weight images, LDS attributes) outside the capture
+                optim.zero_grad(set_to_none=True)
+                model(ids_buf, labels=labels_buf).backward()
+                optim.step()
+        torch.cuda.current_stream().wait_stream(side)
+        optim.zero_grad(set_to_none=True)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            static_loss = model(ids_buf, labels=labels_buf)
+            static_loss.backward()
+            optim.step()
+
+        def step():
+            ids, labels = batch()
+            ids_buf.copy_(ids)
+            labels_buf.copy_(labels)
+            graph.replay()
+            return static_loss
 
     def barrier():
         if world > 1:
@@ -178,7 +207,9 @@ def main():
     gemm_stats = None
     if rank == 0:
         K.GEMM_TRACE = []
-        step()
+        if use_graph:
+            optim.zero_grad(set_to_none=True)
+        eager_step()  # traced eagerly (events between launches), same kernels and shapes as the timed steps
         torch.cuda.synchronize()
         tr = K.GEMM_TRACE
         K.GEMM_TRACE = None
@@ -197,7 +228,7 @@ def main():
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"Llama-3.1-8B text-only LoRA r={args.rank} bf16, seq={S}, 1 sequence per GPU, causal mask, base+LM head frozen "
                                    "(BASELINE.json configs[1]); random-init weights at 8B dimensions" if args.model == "llama31_8b" else f"tiny plumbing config seq={S}",
-                       "global_batch_tokens": S * world, "seq_len": S, "parallelism": f"dp{world}", "loss": round(float(loss.detach()), 4)},
+                       "global_batch_tokens": S * world, "seq_len": S, "parallelism": f"dp{world}", "loss": round(float(loss.detach()), 4), "launch": "hipGraph replay" if use_graph else "eager"},
         }
         gf = GF_PER_TOKEN.get(S)
         if gf and args.model == "llama31_8b":

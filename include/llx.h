@@ -61,6 +61,7 @@ int llx_quantize_int8_rowwise(const void* x, int64_t ldx, void* q, int64_t ldq, 
  *      (README.md:16): allow(q,k) = (k <= q || k < prefix_len[b]) && (!doc_ids || doc_ids[b,q] == doc_ids[b,k]).
  *      q [B,S,H,128], k/v [B,S,KVH,128] with free batch/sequence strides; lse fp32 [B,H,S] (log2 units).
  *      flags: tile classes built by llx_attn_tile_flags (needed only with doc_ids / prefix_len). ----------------- */
+int llx_debug_attn_fwd_occupancy(void); /* diagnostic: workgroups per CU granted to the forward kernel */
 int64_t llx_attn_flags_bytes(int64_t B, int64_t S);
 int llx_attn_tile_flags(const int* doc_ids, const int* prefix_len, void* flags, int64_t B, int64_t S, llx_stream_t s);
 int llx_attn_fwd(const void* q, int64_t q_sb, int64_t q_ss, const void* k, int64_t k_sb, int64_t k_ss, const void* v, int64_t v_sb,

@@ -126,17 +126,34 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnBwdArgs a
   const int srow_in = lane >> 4, sslot = lane & 15;
   const bf16_t* kbase = a.k + (int64_t)b * a.k_sb + kvh * HD;
   const bf16_t* vbase = a.v + (int64_t)b * a.v_sb + kvh * HD;
+  uint32_t koff[4], voff[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = i * 16 + wave * 4 + srow_in;
+    koff[i] = (uint32_t)(((int64_t)row * a.k_ss + (sslot ^ dual_swz(row)) * 8) * 2);  // K: dual-use image (row reads + transposed reads)
+    voff[i] = (uint32_t)(((int64_t)row * a.v_ss + (sslot ^ (row & 15)) * 8) * 2);     // V: row reads only
+  }
   auto stage = [&](int buf, int t) {
     char* sK = smem + buf * DQ_STAGE_BYTES;
     char* sV = sK + TILE_BYTES;
+    if (t * BKV + BKV <= a.S) {
+      const char* kt = (const char*)(kbase + (int64_t)t * BKV * a.k_ss);
+      const char* vt = (const char*)(vbase + (int64_t)t * BKV * a.v_ss);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = i * 16 + wave * 4 + srow_in;
-      const int key = min(t * BKV + row, a.S - 1);
-      const int kc = sslot ^ dual_swz(row);  // K: dual-use image (row reads for S^T, transposed reads for dQ^T)
-      const int vc = sslot ^ (row & 15);     // V: row reads only
-      __builtin_amdgcn_global_load_lds((gbl_void*)(kbase + (int64_t)key * a.k_ss + kc * 8), (lds_void*)(sK + (i * 16 + wave * 4) * 256), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gbl_void*)(vbase + (int64_t)key * a.v_ss + vc * 8), (lds_void*)(sV + (i * 16 + wave * 4) * 256), 16, 0, 0);
+      for (int i = 0; i < 4; ++i) {
+        __builtin_amdgcn_global_load_lds((gbl_void*)(kt + koff[i]), (lds_void*)(sK + (i * 16 + wave * 4) * 256), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_void*)(vt + voff[i]), (lds_void*)(sV + (i * 16 + wave * 4) * 256), 16, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = i * 16 + wave * 4 + srow_in;
+        const int key = min(t * BKV + row, a.S - 1);
+        const int kc = sslot ^ dual_swz(row);
+        const int vc = sslot ^ (row & 15);
+        __builtin_amdgcn_global_load_lds((gbl_void*)(kbase + (int64_t)key * a.k_ss + kc * 8), (lds_void*)(sK + (i * 16 + wave * 4) * 256), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_void*)(vbase + (int64_t)key * a.v_ss + vc * 8), (lds_void*)(sV + (i * 16 + wave * 4) * 256), 16, 0, 0);
+      }
     }
   };
 
@@ -282,19 +299,36 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv2_kernel(const AttnBwdArgs
   const int srow_in = lane >> 4, sslot = lane & 15;
   const bf16_t* qbase = a.q + (int64_t)b * a.q_sb + h * HD;
   const bf16_t* dbase = a.d_o + (int64_t)b * a.do_sb + h * HD;
+  uint32_t qoff[4], doff[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = i * 16 + wave * 4 + srow_in;
+    qoff[i] = (uint32_t)(((int64_t)row * a.q_ss + (sslot ^ dual_swz(row)) * 8) * 2);
+    doff[i] = (uint32_t)(((int64_t)row * a.do_ss + (sslot ^ dual_swz(row)) * 8) * 2);
+  }
   auto stage = [&](int buf, int qt) {
     char* sQ = smem + buf * DKV_STAGE_BYTES;
     char* sD = sQ + TILE_BYTES;
     char* sL = sD + TILE_BYTES;
+    if (qt * DKV_QT + DKV_QT <= a.S) {
+      const char* qtile = (const char*)(qbase + (int64_t)qt * DKV_QT * a.q_ss);
+      const char* dtile = (const char*)(dbase + (int64_t)qt * DKV_QT * a.do_ss);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = i * 16 + wave * 4 + srow_in;
-      const int qr = min(qt * DKV_QT + row, a.S - 1);
-      const int c = sslot ^ dual_swz(row);
-      __builtin_amdgcn_global_load_lds((gbl_void*)(qbase + (int64_t)qr * a.q_ss + c * 8), (lds_void*)(sQ + (i * 16 + wave * 4) * 256), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gbl_void*)(dbase + (int64_t)qr * a.do_ss + c * 8), (lds_void*)(sD + (i * 16 + wave * 4) * 256), 16, 0, 0);
+      for (int i = 0; i < 4; ++i) {
+        __builtin_amdgcn_global_load_lds((gbl_void*)(qtile + qoff[i]), (lds_void*)(sQ + (i * 16 + wave * 4) * 256), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_void*)(dtile + doff[i]), (lds_void*)(sD + (i * 16 + wave * 4) * 256), 16, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = i * 16 + wave * 4 + srow_in;
+        const int qr = min(qt * DKV_QT + row, a.S - 1);
+        const int c = sslot ^ dual_swz(row);
+        __builtin_amdgcn_global_load_lds((gbl_void*)(qbase + (int64_t)qr * a.q_ss + c * 8), (lds_void*)(sQ + (i * 16 + wave * 4) * 256), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_void*)(dbase + (int64_t)qr * a.do_ss + c * 8), (lds_void*)(sD + (i * 16 + wave * 4) * 256), 16, 0, 0);
+      }
     }
-    if (wave < 2) {
+    if (wave < 2) {  // wave 0: lse[64], wave 1: delta[64]
       const float* src = (wave == 0 ? a.lse : a.delta) + ((int64_t)b * a.H + h) * a.S + min(qt * DKV_QT + lane, a.S - 1);
       __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(sL + wave * 256), 4, 0, 0);
     }

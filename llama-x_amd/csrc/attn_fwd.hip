@@ -15,6 +15,7 @@
 //                   come from the row-major LDS tile through ds_read_b64_tr_b16)
 // K/V tiles are double-buffered in LDS by global_load_lds with the bank swizzle applied on the source address.
 #include "common.h"
+#include <stdlib.h>
 
 #define HD 128
 #define BQ 128
@@ -75,19 +76,35 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnFwdArgs a) {
   const int srow_in = lane >> 4, sslot = lane & 15;
   const bf16_t* kbase = a.k + (int64_t)b * a.k_sb + kvh * HD;
   const bf16_t* vbase = a.v + (int64_t)b * a.v_sb + kvh * HD;
+  // loop-invariant per-lane byte offsets inside a tile; the wave-uniform tile base advances by 64 rows per tile
+  uint32_t koff[4], voff[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = i * 16 + wave * 4 + srow_in;
+    koff[i] = (uint32_t)(((int64_t)row * a.k_ss + (sslot ^ (row & 15)) * 8) * 2);          // K image: slot = chunk ^ (row & 15)
+    voff[i] = (uint32_t)(((int64_t)row * a.v_ss + (sslot ^ ((row & 3) << 2)) * 8) * 2);    // V image: slot = chunk ^ ((row & 3) << 2)
+  }
   auto stage = [&](int buf, int t) {
     char* sK = smem + buf * ATT_STAGE_BYTES;
     char* sV = sK + KV_TILE_BYTES;
+    if (t * BKV + BKV <= a.S) {  // full tile: uniform base + invariant lane offset, no vector address arithmetic
+      const char* kt = (const char*)(kbase + (int64_t)t * BKV * a.k_ss);
+      const char* vt = (const char*)(vbase + (int64_t)t * BKV * a.v_ss);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = i * 16 + wave * 4 + srow_in;
-      const int key = min(t * BKV + row, a.S - 1);
-      const int kc = sslot ^ (row & 15);          // K image: slot = chunk ^ (row & 15)
-      const int vc = sslot ^ ((row & 3) << 2);    // V image: slot = chunk ^ ((row & 3) << 2)
-      __builtin_amdgcn_global_load_lds((gbl_void*)(kbase + (int64_t)key * a.k_ss + kc * 8),
-                                       (lds_void*)(sK + (i * 16 + wave * 4) * 256), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gbl_void*)(vbase + (int64_t)key * a.v_ss + vc * 8),
-                                       (lds_void*)(sV + (i * 16 + wave * 4) * 256), 16, 0, 0);
+      for (int i = 0; i < 4; ++i) {
+        __builtin_amdgcn_global_load_lds((gbl_void*)(kt + koff[i]), (lds_void*)(sK + (i * 16 + wave * 4) * 256), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_void*)(vt + voff[i]), (lds_void*)(sV + (i * 16 + wave * 4) * 256), 16, 0, 0);
+      }
+    } else {  // ragged last tile: clamp rows past the end (they are masked out)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = i * 16 + wave * 4 + srow_in;
+        const int key = min(t * BKV + row, a.S - 1);
+        const int kc = sslot ^ (row & 15);
+        const int vc = sslot ^ ((row & 3) << 2);
+        __builtin_amdgcn_global_load_lds((gbl_void*)(kbase + (int64_t)key * a.k_ss + kc * 8), (lds_void*)(sK + (i * 16 + wave * 4) * 256), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_void*)(vbase + (int64_t)key * a.v_ss + vc * 8), (lds_void*)(sV + (i * 16 + wave * 4) * 256), 16, 0, 0);
+      }
     }
   };
 
@@ -281,8 +298,26 @@ extern "C" int llx_attn_fwd(const void* q, int64_t q_sb, int64_t q_ss, const voi
   a.doc_ids = doc_ids; a.prefix_len = prefix_len; a.flags = (doc_ids || prefix_len) ? (const uint8_t*)flags : nullptr;
   a.B = (int)B; a.S = (int)S; a.H = (int)H; a.KVH = (int)KVH;
   a.scale_log2 = scale * 1.4426950408889634f;
-  if (a.flags) hipLaunchKernelGGL(attn_fwd_kernel<true>, dim3((unsigned)cdiv64(S, BQ), (unsigned)H, (unsigned)B), dim3(256), ATT_LDS_BYTES, stream, a);
-  else hipLaunchKernelGGL(attn_fwd_kernel<false>, dim3((unsigned)cdiv64(S, BQ), (unsigned)H, (unsigned)B), dim3(256), ATT_LDS_BYTES, stream, a);
+  static int lds_bytes = 0;
+  if (!lds_bytes) {  // LLX_ATTN_LDS_PAD=1: experiment knob - ask for 96 KiB so that only ONE workgroup fits a CU
+    const char* e = getenv("LLX_ATTN_LDS_PAD");
+    lds_bytes = (e && e[0] == '1') ? 96 * 1024 : ATT_LDS_BYTES;
+    if (lds_bytes != ATT_LDS_BYTES) {
+      hipFuncSetAttribute((const void*)attn_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+      hipFuncSetAttribute((const void*)attn_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    }
+  }
+  if (a.flags) hipLaunchKernelGGL(attn_fwd_kernel<true>, dim3((unsigned)cdiv64(S, BQ), (unsigned)H, (unsigned)B), dim3(256), lds_bytes, stream, a);
+  else hipLaunchKernelGGL(attn_fwd_kernel<false>, dim3((unsigned)cdiv64(S, BQ), (unsigned)H, (unsigned)B), dim3(256), lds_bytes, stream, a);
   LLX_LAUNCH_CHECK("llx_attn_fwd");
   return LLX_OK;
+}
+
+// Diagnostic: resident workgroups per CU the runtime grants the forward kernel (occupancy API; advisory).
+extern "C" int llx_debug_attn_fwd_occupancy(void) {
+  int n = -1;
+  hipFuncSetAttribute((const void*)attn_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS_BYTES);
+  hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)attn_fwd_kernel<false>, 256, ATT_LDS_BYTES);
+  if (e != hipSuccess) { llx_set_error("occupancy query: %s", hipGetErrorString(e)); return -1; }
+  return n;
 }

@@ -78,23 +78,33 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const GemmArgs g) {
   const int nk1 = g.K / TK;
   const int nk = nk1 + g.K2 / TK;
 
-  auto stage = [&](int buf, int kt) {
-    char* sA = smem + buf * STAGE_BYTES;
-    char* sB = sA + A_TILE_BYTES;
-    const char* Ap; const char* Bp; int64_t la, lb; int k0;  // byte pointers / byte strides / byte offset
-    if (kt < nk1) { Ap = (const char*)g.A; Bp = (const char*)g.B; la = g.lda * ESZ; lb = g.ldb * ESZ; k0 = kt * 128; }
-    else { Ap = (const char*)g.A2; Bp = (const char*)g.B2; la = g.lda2 * ESZ; lb = g.ldb2 * ESZ; k0 = (kt - nk1) * 128; }
+  // Per-lane source offsets are loop invariant (row * stride + swizzled chunk, 32-bit bytes); per K-tile only the
+  // wave-uniform base pointer advances, so the loads need no vector address arithmetic inside the loop.
+  uint32_t aoff[4], boff[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const char* src = Ap + (int64_t)arow[i] * la + k0 + schunk * 16;
-      __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(sA + (i * 512 + wave * 64) * 16), 16, 0, 0);
-    }
+  for (int i = 0; i < 4; ++i) {
+    aoff[i] = (uint32_t)((int64_t)arow[i] * g.lda * ESZ + schunk * 16);
+    boff[i] = (uint32_t)((int64_t)brow[i] * g.ldb * ESZ + schunk * 16);
+  }
+  // half = 0: the A tile, half = 1: the B tile (4 x 16-B global_load_lds per thread each)
+  auto stage_half = [&](int buf, int kt, int half) {
+    char* sT = smem + buf * STAGE_BYTES + half * A_TILE_BYTES;
+    if (kt < nk1) {
+      const char* base = (const char*)(half ? g.B : g.A) + (int64_t)kt * 128;  // wave-uniform
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const char* src = Bp + (int64_t)brow[i] * lb + k0 + schunk * 16;
-      __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(sB + (i * 512 + wave * 64) * 16), 16, 0, 0);
+      for (int i = 0; i < 4; ++i)
+        __builtin_amdgcn_global_load_lds((gbl_void*)(base + (half ? boff[i] : aoff[i])), (lds_void*)(sT + (i * 512 + wave * 64) * 16), 16, 0, 0);
+    } else {  // K-extension tiles (LoRA operands): a different pointer / stride pair, at most a few tiles per launch
+      const char* base = (const char*)(half ? g.B2 : g.A2) + (int64_t)(kt - nk1) * 128;
+      const int64_t l = (half ? g.ldb2 : g.lda2) * ESZ;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const char* src = base + (int64_t)(half ? brow[i] : arow[i]) * l + schunk * 16;
+        __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(sT + (i * 512 + wave * 64) * 16), 16, 0, 0);
+      }
     }
   };
+  auto stage = [&](int buf, int kt) { stage_half(buf, kt, 0); stage_half(buf, kt, 1); };
 
   // ---- fragment read offsets (bytes inside a tile): row*128 + ((ks*4 + (lane>>4)) ^ ((lane>>1)&7))*16
   const int frow = lane & 15;
@@ -118,11 +128,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const GemmArgs g) {
 
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
-    if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
     const char* sA = smem + cur * STAGE_BYTES;
     const char* sB = sA + A_TILE_BYTES;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
+      if (kt + 1 < nk) stage_half(cur ^ 1, kt + 1, ks);  // spread the next tile's loads over the two k-steps
       const int slot = ks ? slot1 : slot0;
       // 16-byte fragments: 8 bf16 (k = 8*(lane>>4)+j) or 16 int8 (k = 16*(lane>>4)+j) -- same bytes, same addresses
       i32x4_t af[8], bfr[4];
@@ -130,6 +140,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const GemmArgs g) {
       for (int ni = 0; ni < 4; ++ni) bfr[ni] = *reinterpret_cast<const i32x4_t*>(sB + b_base + ni * 16 * 128 + slot);
 #pragma unroll
       for (int mi = 0; mi < 8; ++mi) af[mi] = *reinterpret_cast<const i32x4_t*>(sA + a_base + mi * 16 * 128 + slot);
+      __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int mi = 0; mi < 8; ++mi)
 #pragma unroll
@@ -140,6 +151,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const GemmArgs g) {
             acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, bfr[ni]), __builtin_bit_cast(bf16x8_t, af[mi]),
                                                                   acc[mi][ni], 0, 0, 0);
         }
+      __builtin_amdgcn_s_setprio(0);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -239,6 +251,7 @@ extern "C" int llx_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64
   LLX_REQUIRE(epilogue == EPI_NONE || (E && (uintptr_t)E % 16 == 0), "llx_gemm_nt_bf16: epilogue operand missing/unaligned");
   LLX_REQUIRE(epilogue != EPI_RESIDUAL || lde % 8 == 0, "llx_gemm_nt_bf16: residual stride must be a multiple of 8");
   LLX_REQUIRE(M < (1 << 30) && N < (1 << 30) && K < (1 << 30), "llx_gemm_nt_bf16: dimension too large");
+  LLX_REQUIRE(M * lda * 2 < (int64_t)4294967296 && N * ldb * 2 < (int64_t)4294967296, "llx_gemm_nt_bf16: operand larger than 4 GiB (32-bit tile offsets)");
   GemmArgs a;
   a.A = (const bf16_t*)A; a.B = (const bf16_t*)B; a.C = (bf16_t*)C;
   a.A2 = (const bf16_t*)A2; a.B2 = (const bf16_t*)B2; a.E = (const bf16_t*)E; a.E2 = nullptr;

@@ -12,7 +12,7 @@ from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
 import torch  # noqa: F401  (must be imported first: it loads the HIP runtime this library binds to)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libllx_hip.so")
+LIB_PATH = os.environ.get("LLX_LIB_PATH") or os.path.join(_HERE, "libllx_hip.so")  # override: A/B of kernel builds
 
 _lib = None
 
@@ -25,6 +25,7 @@ SIGNATURES: dict[str, tuple] = {
     "llx_rmsnorm_fwd": (c_int, [_P, _P, _P, _P, _L, _L, _F, _P]),
     "llx_rmsnorm_bwd_workspace_bytes": (c_int64, [_L, _L]),
     "llx_rmsnorm_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _I, _P, _L, _L, _P]),
+    "llx_debug_attn_fwd_occupancy": (c_int, []),
     "llx_attn_flags_bytes": (c_int64, [_L, _L]),
     "llx_attn_tile_flags": (c_int, [_P, _P, _P, _L, _L, _P]),
     "llx_attn_fwd": (c_int, [_P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _P, _P, _P, _L, _L, _L, _L, _L, _F, _P]),
@@ -89,7 +90,13 @@ def check(rc: int, what: str = ""):
         raise LlxError(f"{what} failed (code {rc}): {msg.decode() if msg else '?'}")
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream() -> c_void_p:
+    """hipStream_t of torch's current stream on the current device (the fast raw accessor when torch exposes it)."""
+    if _raw_stream is not None:
+        return c_void_p(_raw_stream(torch.cuda.current_device()))
     return c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
