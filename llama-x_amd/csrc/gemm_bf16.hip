@@ -12,6 +12,7 @@
 // consecutive output columns; the epilogue stages the bf16 tile through LDS and stores whole 512-B rows.
 #include "common.h"
 #include <type_traits>
+#include <stdlib.h>
 
 #define BM 256
 #define BN 256
@@ -40,7 +41,7 @@ __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + e
 
 // I8 = true: A/B are int8 (K counted in int8 elements, 128 per tile row = the same 128-byte rows), MFMA is
 // v_mfma_i32_16x16x64_i8 with int32 accumulators, epilogue EPI_ROWCOLSCALE (torchao::int8_mm_dequant).
-template <int EPI, bool I8>
+template <int EPI, bool I8, int PIPE>
 __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const GemmArgs g) {
   constexpr int ESZ = I8 ? 1 : 2;         // bytes per element
   constexpr int TK = 128 / ESZ;           // elements per 128-byte tile row (64 bf16 | 128 int8)
@@ -122,39 +123,142 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const GemmArgs g) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = acc_t{0, 0, 0, 0};
 
-  stage(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    const char* sA = smem + cur * STAGE_BYTES;
-    const char* sB = sA + A_TILE_BYTES;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      if (kt + 1 < nk) stage_half(cur ^ 1, kt + 1, ks);  // spread the next tile's loads over the two k-steps
-      const int slot = ks ? slot1 : slot0;
-      // 16-byte fragments: 8 bf16 (k = 8*(lane>>4)+j) or 16 int8 (k = 16*(lane>>4)+j) -- same bytes, same addresses
-      i32x4_t af[8], bfr[4];
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni) bfr[ni] = *reinterpret_cast<const i32x4_t*>(sB + b_base + ni * 16 * 128 + slot);
-#pragma unroll
-      for (int mi = 0; mi < 8; ++mi) af[mi] = *reinterpret_cast<const i32x4_t*>(sA + a_base + mi * 16 * 128 + slot);
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int mi = 0; mi < 8; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
-          if constexpr (I8)
-            acc[mi][ni] = __builtin_amdgcn_mfma_i32_16x16x64_i8(bfr[ni], af[mi], acc[mi][ni], 0, 0, 0);
-          else
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, bfr[ni]), __builtin_bit_cast(bf16x8_t, af[mi]),
-                                                                  acc[mi][ni], 0, 0, 0);
-        }
-      __builtin_amdgcn_s_setprio(0);
-    }
+  if constexpr (PIPE == 0) {
+    stage(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+      const int cur = kt & 1;
+      const char* sA = smem + cur * STAGE_BYTES;
+      const char* sB = sA + A_TILE_BYTES;
+  #pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        if (kt + 1 < nk) stage_half(cur ^ 1, kt + 1, ks);  // spread the next tile's loads over the two k-steps
+        const int slot = ks ? slot1 : slot0;
+        // 16-byte fragments: 8 bf16 (k = 8*(lane>>4)+j) or 16 int8 (k = 16*(lane>>4)+j) -- same bytes, same addresses
+        i32x4_t af[8], bfr[4];
+  #pragma unroll
+        for (int ni = 0; ni < 4; ++ni) bfr[ni] = *reinterpret_cast<const i32x4_t*>(sB + b_base + ni * 16 * 128 + slot);
+  #pragma unroll
+        for (int mi = 0; mi < 8; ++mi) af[mi] = *reinterpret_cast<const i32x4_t*>(sA + a_base + mi * 16 * 128 + slot);
+        __builtin_amdgcn_s_setprio(1);
+  #pragma unroll
+        for (int mi = 0; mi < 8; ++mi)
+  #pragma unroll
+          for (int ni = 0; ni < 4; ++ni) {
+            if constexpr (I8)
+              acc[mi][ni] = __builtin_amdgcn_mfma_i32_16x16x64_i8(bfr[ni], af[mi], acc[mi][ni], 0, 0, 0);
+            else
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, bfr[ni]), __builtin_bit_cast(bf16x8_t, af[mi]),
+                                                                    acc[mi][ni], 0, 0, 0);
+          }
+        __builtin_amdgcn_s_setprio(0);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+  } else {
+    // ---- deep pipeline: 4 phases per K-tile (one 64x32 accumulator quadrant = 16 MFMAs each), one 16-KiB half-tile
+    // (A rows 0-127 | A rows 128-255 | B rows 0-127 | B rows 128-255) staged per phase, loads kept in flight ACROSS the
+    // barriers behind a counted vmcnt.  Half-tiles of K-tile T are issued:  B-lo, B-hi, A-lo in phases 1,2,3 of tile T-2
+    // and A-hi in phase 0 of tile T-1, i.e. 5-7 phases before their first read.  LDS reuse (same 2 x 64 KiB stages):
+    //   B(t) is read only in phase 0 (both 32-column halves stay in registers) -> free for B(t+2) after the phase-0 barrier
+    //   A(t) is read in phases 0 and 2 -> free for A(t+2) after the phase-2 barrier.
+    auto stage_q = [&](int kt, int which) {  // which: 0 A-lo, 1 A-hi, 2 B-lo, 3 B-hi of K-tile kt into stage kt&1
+      if (kt >= nk) return;
+      const int half = which >> 1, hi = which & 1;
+      char* sT = smem + (kt & 1) * STAGE_BYTES + half * A_TILE_BYTES + hi * (A_TILE_BYTES / 2);
+      if (kt < nk1) {
+        const char* base = (const char*)(half ? g.B : g.A) + (int64_t)kt * 128;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          __builtin_amdgcn_global_load_lds((gbl_void*)(base + (half ? boff[2 * hi + j] : aoff[2 * hi + j])), (lds_void*)(sT + (j * 512 + wave * 64) * 16), 16, 0, 0);
+      } else {
+        const char* base = (const char*)(half ? g.B2 : g.A2) + (int64_t)(kt - nk1) * 128;
+        const int64_t l = (half ? g.ldb2 : g.lda2) * ESZ;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const char* src = base + (int64_t)(half ? brow[2 * hi + j] : arow[2 * hi + j]) * l + schunk * 16;
+          __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(sT + (j * 512 + wave * 64) * 16), 16, 0, 0);
+        }
+      }
+    };
+    auto mfma = [&](const i32x4_t& b, const i32x4_t& a, acc_t& c) {
+      if constexpr (I8) c = __builtin_amdgcn_mfma_i32_16x16x64_i8(b, a, c, 0, 0, 0);
+      else c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, b), __builtin_bit_cast(bf16x8_t, a), c, 0, 0, 0);
+    };
+    // prologue: all of tile 0, then B-lo, B-hi, A-lo of tile 1
+    stage_q(0, 0); stage_q(0, 1); stage_q(0, 2); stage_q(0, 3);
+    stage_q(1, 2); stage_q(1, 3); stage_q(1, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+      const char* sA = smem + (kt & 1) * STAGE_BYTES;
+      const char* sB = sA + A_TILE_BYTES;
+      // ---------------- phase 0: tile kt has landed once all but the 6 youngest loads (3 half-tiles of kt+1) are done
+      if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      stage_q(kt + 1, 1);  // A-hi of the next tile (its stage's A-hi was last read in phase 2 of tile kt-1)
+      i32x4_t bfr[2][4], af[8];  // bfr[ks][nh*2 + n2], af[ks*4 + m4]
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) bfr[ks][ni] = *reinterpret_cast<const i32x4_t*>(sB + b_base + ni * 16 * 128 + (ks ? slot1 : slot0));
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int m4 = 0; m4 < 4; ++m4) af[ks * 4 + m4] = *reinterpret_cast<const i32x4_t*>(sA + a_base + m4 * 16 * 128 + (ks ? slot1 : slot0));
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int m4 = 0; m4 < 4; ++m4)
+#pragma unroll
+          for (int n2 = 0; n2 < 2; ++n2) mfma(bfr[ks][n2], af[ks * 4 + m4], acc[m4][n2]);
+      __builtin_amdgcn_s_setprio(0);
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_s_barrier();  // every wave has its B fragments: B(kt) may be overwritten
+      asm volatile("" ::: "memory");
+      // ---------------- phase 1: quadrant (rows 0-63, cols 32-63)
+      stage_q(kt + 2, 2);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int m4 = 0; m4 < 4; ++m4)
+#pragma unroll
+          for (int n2 = 0; n2 < 2; ++n2) mfma(bfr[ks][2 + n2], af[ks * 4 + m4], acc[m4][2 + n2]);
+      __builtin_amdgcn_s_setprio(0);
+      // ---------------- phase 2: quadrant (rows 64-127, cols 32-63)
+      stage_q(kt + 2, 3);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int m4 = 0; m4 < 4; ++m4) af[ks * 4 + m4] = *reinterpret_cast<const i32x4_t*>(sA + a_base + (4 + m4) * 16 * 128 + (ks ? slot1 : slot0));
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int m4 = 0; m4 < 4; ++m4)
+#pragma unroll
+          for (int n2 = 0; n2 < 2; ++n2) mfma(bfr[ks][2 + n2], af[ks * 4 + m4], acc[4 + m4][2 + n2]);
+      __builtin_amdgcn_s_setprio(0);
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_s_barrier();  // every wave has its second A half: A(kt) may be overwritten
+      asm volatile("" ::: "memory");
+      // ---------------- phase 3: quadrant (rows 64-127, cols 0-31)
+      stage_q(kt + 2, 0);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int m4 = 0; m4 < 4; ++m4)
+#pragma unroll
+          for (int n2 = 0; n2 < 2; ++n2) mfma(bfr[ks][n2], af[ks * 4 + m4], acc[4 + m4][n2]);
+      __builtin_amdgcn_s_setprio(0);
+    }
+    __syncthreads();  // all LDS reads done before the epilogue reuses the stages
   }
 
   // ---- epilogue: acc (C^T fragments: lane owns n = fq*4..+4 for m = frow) -> bf16 -> LDS tile -> coalesced rows.
@@ -216,22 +320,39 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const GemmArgs g) {
   }
 }
 
-static bool g_attr_set[8] = {false};
+#ifndef LLX_GEMM_PIPE_DEFAULT
+#define LLX_GEMM_PIPE_DEFAULT 1
+#endif
 
-template <int EPI, bool I8 = false>
-static int launch_gemm(const GemmArgs& a, hipStream_t stream) {
-  auto kern = gemm_nt_kernel<EPI, I8>;
-  if (!g_attr_set[EPI]) {
+static int gemm_pipe_mode() {
+  static int mode = -1;
+  if (mode < 0) {
+    const char* e = getenv("LLX_GEMM_PIPE");
+    mode = e ? (e[0] == '0' ? 0 : 1) : LLX_GEMM_PIPE_DEFAULT;
+  }
+  return mode;
+}
+
+template <int EPI, bool I8, int PIPE>
+static int launch_gemm_p(const GemmArgs& a, hipStream_t stream) {
+  auto kern = gemm_nt_kernel<EPI, I8, PIPE>;
+  static bool attr_set = false;
+  if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
     if (e != hipSuccess) {
       llx_set_error("llx_gemm_nt_bf16: cannot raise dynamic LDS limit: %s", hipGetErrorString(e));
       return LLX_ERR_LAUNCH;
     }
-    g_attr_set[EPI] = true;
+    attr_set = true;
   }
   hipLaunchKernelGGL(kern, dim3(a.grid_m * a.grid_n), dim3(512), GEMM_LDS_BYTES, stream, a);
   LLX_LAUNCH_CHECK("llx_gemm_nt_bf16");
   return LLX_OK;
+}
+
+template <int EPI, bool I8 = false>
+static int launch_gemm(const GemmArgs& a, hipStream_t stream) {
+  return gemm_pipe_mode() ? launch_gemm_p<EPI, I8, 1>(a, stream) : launch_gemm_p<EPI, I8, 0>(a, stream);
 }
 
 // C[M,N] = A[M,K].B[N,K]^T (+ A2[M,K2].B2[N,K2]^T), bf16 in/out, fp32 accumulate.
