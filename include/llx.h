@@ -35,7 +35,8 @@ int llx_device_info(int device, char* name, int len);    /* returns CU count, fi
 int llx_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int64_t rows, int64_t dim, float eps, llx_stream_t s);
 int64_t llx_rmsnorm_bwd_workspace_bytes(int64_t rows, int64_t dim);
 int llx_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rstd, void* dx, void* dw /*nullable*/,
-                    int dw_accumulate, void* workspace, int64_t rows, int64_t dim, llx_stream_t s);
+                    int dw_accumulate, void* workspace, const void* dres /*nullable: residual-branch gradient added to dx*/,
+                    int64_t rows, int64_t dim, llx_stream_t s);
 
 /* ---- bf16 MFMA GEMM, C[M,N] = A[M,K].B[N,K]^T (+ A2[M,K2].B2[N,K2]^T): every F.linear of the layer
  *      (modelling/llama.py:118-120,140,152,216), its data gradients (on a transposed weight image), the LoRA adapter
@@ -112,6 +113,8 @@ int64_t llx_skinny_tn_workspace_bytes(int64_t M, int64_t N, int64_t R);
 int llx_skinny_tn(const void* U, const void* Y, int64_t ldy, void* out, int64_t out_ld, int64_t M, int64_t N, int64_t R, float scale,
                   int transpose_out, int accumulate, void* workspace, llx_stream_t s);
 int llx_pad64(const void* in, int64_t ld, void* out, int64_t R, int64_t C, float scale, int transpose, llx_stream_t s);
+int llx_lora_group_pack(const void* const* lora_a, const void* const* lora_b, const int64_t* Ns, const int64_t* ranks, int nm, int64_t K,
+                        float scale, void* a_cat, void* b2, void* bT, void* a2t, llx_stream_t s);  /* all four images, one launch (host arrays) */
 int llx_lora_pack(const void* in, int64_t ld, void* out, int64_t out_ld, int64_t R, int64_t C, int64_t row_off, int64_t col_off, float scale,
                   int transpose, llx_stream_t s);   /* batched LoRA operand images of a linear group (q|k|v, gate|up) */
 

@@ -320,3 +320,76 @@ extern "C" int llx_lora_pack(const void* in, int64_t ld, void* out, int64_t out_
   LLX_LAUNCH_CHECK("llx_lora_pack");
   return LLX_OK;
 }
+
+// All four batched LoRA operand images of a linear group in ONE launch (forward builds them, backward reuses them):
+//   a_cat [R, K]      rows r_off_i.. = lora_a_i                       (B operand of t = x @ A_cat^T)
+//   b2    [N, 64]     block (n_off_i.., r_off_i..) = s * lora_b_i     (K-extension operand of the forward GEMM)
+//   bT    [R, N]      block (r_off_i.., n_off_i..) = lora_b_i^T       (B operand of u = dy @ B_blk)
+//   a2t   [K, 64]     cols r_off_i.. = s * lora_a_i^T                 (K-extension operand of the dgrad GEMM)
+struct LoraMember { const bf16_t* a; const bf16_t* b; int N, n_off, r, r_off; };
+struct LoraGroup { LoraMember m[4]; int nm, K, N, R; float scale; bf16_t* a_cat; bf16_t* b2; bf16_t* bT; bf16_t* a2t; };
+
+__global__ void lora_group_pack_kernel(const LoraGroup g) {
+  const int64_t n_acat = (int64_t)g.R * g.K, n_b2 = (int64_t)g.N * 64, n_bT = (int64_t)g.R * g.N, n_a2t = (int64_t)g.K * 64;
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < n_acat) {  // a_cat[r][k]
+    const int r = (int)(idx / g.K), k = (int)(idx % g.K);
+    bf16_t v = 0;
+    for (int i = 0; i < g.nm; ++i)
+      if (r >= g.m[i].r_off && r < g.m[i].r_off + g.m[i].r) v = g.m[i].a[(int64_t)(r - g.m[i].r_off) * g.K + k];
+    g.a_cat[idx] = v;
+    return;
+  }
+  idx -= n_acat;
+  if (idx < n_b2) {  // b2[n][c]
+    const int n = (int)(idx >> 6), c = (int)(idx & 63);
+    float v = 0.f;
+    for (int i = 0; i < g.nm; ++i) {
+      const LoraMember& m = g.m[i];
+      if (n >= m.n_off && n < m.n_off + m.N && c >= m.r_off && c < m.r_off + m.r) v = bf2f(m.b[(int64_t)(n - m.n_off) * m.r + (c - m.r_off)]) * g.scale;
+    }
+    g.b2[idx] = f2bf(v);
+    return;
+  }
+  idx -= n_b2;
+  if (idx < n_bT) {  // bT[r][n]
+    const int r = (int)(idx / g.N), n = (int)(idx % g.N);
+    bf16_t v = 0;
+    for (int i = 0; i < g.nm; ++i) {
+      const LoraMember& m = g.m[i];
+      if (n >= m.n_off && n < m.n_off + m.N && r >= m.r_off && r < m.r_off + m.r) v = m.b[(int64_t)(n - m.n_off) * m.r + (r - m.r_off)];
+    }
+    g.bT[idx] = v;
+    return;
+  }
+  idx -= n_bT;
+  if (idx < n_a2t) {  // a2t[k][c]
+    const int k = (int)(idx >> 6), c = (int)(idx & 63);
+    float v = 0.f;
+    for (int i = 0; i < g.nm; ++i) {
+      const LoraMember& m = g.m[i];
+      if (c >= m.r_off && c < m.r_off + m.r) v = bf2f(m.a[(int64_t)(c - m.r_off) * g.K + k]) * g.scale;
+    }
+    g.a2t[idx] = f2bf(v);
+  }
+}
+
+// members: arrays of length nm (<= 4): lora_a[i] [r_i, K] and lora_b[i] [N_i, r_i], both contiguous.
+extern "C" int llx_lora_group_pack(const void* const* lora_a, const void* const* lora_b, const int64_t* Ns, const int64_t* ranks, int nm, int64_t K,
+                                   float scale, void* a_cat, void* b2, void* bT, void* a2t, hipStream_t stream) {
+  LLX_REQUIRE(lora_a && lora_b && Ns && ranks && nm >= 1 && nm <= 4 && a_cat && b2 && bT && a2t, "llx_lora_group_pack: bad arguments");
+  LoraGroup g;
+  int n_off = 0, r_off = 0;
+  for (int i = 0; i < nm; ++i) {
+    g.m[i].a = (const bf16_t*)lora_a[i]; g.m[i].b = (const bf16_t*)lora_b[i];
+    g.m[i].N = (int)Ns[i]; g.m[i].n_off = n_off; g.m[i].r = (int)ranks[i]; g.m[i].r_off = r_off;
+    n_off += (int)Ns[i]; r_off += (int)ranks[i];
+  }
+  LLX_REQUIRE(r_off <= 64, "llx_lora_group_pack: total rank %d > 64", r_off);
+  g.nm = nm; g.K = (int)K; g.N = n_off; g.R = r_off; g.scale = scale;
+  g.a_cat = (bf16_t*)a_cat; g.b2 = (bf16_t*)b2; g.bT = (bf16_t*)bT; g.a2t = (bf16_t*)a2t;
+  const int64_t total = (int64_t)g.R * g.K + (int64_t)g.N * 64 + (int64_t)g.R * g.N + (int64_t)g.K * 64;
+  hipLaunchKernelGGL(lora_group_pack_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, stream, g);
+  LLX_LAUNCH_CHECK("llx_lora_group_pack");
+  return LLX_OK;
+}

@@ -58,7 +58,7 @@ template <int NCH>
 __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
                                                           const bf16_t* __restrict__ w, const float* __restrict__ rstd,
                                                           bf16_t* __restrict__ dx, float* __restrict__ dw_partial,
-                                                          int64_t rows, int dim, int rows_per_block) {
+                                                          const bf16_t* __restrict__ dres, int64_t rows, int dim, int rows_per_block) {
   __shared__ float red[16];
   const int t = threadIdx.x;
   float wv[NCH][8];
@@ -106,10 +106,16 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restri
       const int col = c * 2048 + t * 8;
       if (col < dim) {
         u32x4_t o;
+        u32x4_t rv = {0u, 0u, 0u, 0u};
+        if (dres) rv = *reinterpret_cast<const u32x4_t*>(dres + row * dim + col);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           float a = rs * (g[c][2 * e] - xh[c][2 * e] * m);
           float b = rs * (g[c][2 * e + 1] - xh[c][2 * e + 1] * m);
+          if (dres) {  // gradient of the residual branch joins here: bf16(dx) + dres, rounded as the eager add would
+            a = bf2f(f2bf(a)) + bflo(rv[e]);
+            b = bf2f(f2bf(b)) + bfhi(rv[e]);
+          }
           o[e] = pack_bf2(a, b);
         }
         *reinterpret_cast<u32x4_t*>(dx + row * dim + col) = o;
@@ -169,8 +175,9 @@ extern "C" int64_t llx_rmsnorm_bwd_workspace_bytes(int64_t rows, int64_t dim) {
 }
 
 // dw may be null (frozen norm weight). workspace: llx_rmsnorm_bwd_workspace_bytes(rows, dim) bytes of fp32.
+// dres (nullable): gradient arriving through the residual connection around the normed branch; added to dx in the same pass.
 extern "C" int llx_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rstd, void* dx, void* dw,
-                               int dw_accumulate, void* workspace, int64_t rows, int64_t dim, hipStream_t stream) {
+                               int dw_accumulate, void* workspace, const void* dres, int64_t rows, int64_t dim, hipStream_t stream) {
   LLX_REQUIRE(dy && x && w && rstd && dx, "llx_rmsnorm_bwd: null pointer");
   LLX_REQUIRE(dim > 0 && dim % 8 == 0 && dim <= 8192, "llx_rmsnorm_bwd: dim=%lld must be a multiple of 8 and <= 8192", (long long)dim);
   LLX_REQUIRE(!dw || workspace, "llx_rmsnorm_bwd: workspace required when dw is requested");
@@ -179,7 +186,7 @@ extern "C" int llx_rmsnorm_bwd(const void* dy, const void* x, const void* w, con
   const int nblk = (int)cdiv64(rows, rpb);
   const int nch = (int)cdiv64(dim, 2048);
   float* part = dw ? (float*)workspace : nullptr;
-#define L(N) hipLaunchKernelGGL(rmsnorm_bwd_kernel<N>, dim3(nblk), dim3(256), 0, stream, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)w, rstd, (bf16_t*)dx, part, rows, (int)dim, rpb)
+#define L(N) hipLaunchKernelGGL(rmsnorm_bwd_kernel<N>, dim3(nblk), dim3(256), 0, stream, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)w, rstd, (bf16_t*)dx, part, (const bf16_t*)dres, rows, (int)dim, rpb)
   if (nch <= 1) L(1); else if (nch <= 2) L(2); else L(4);
 #undef L
   LLX_LAUNCH_CHECK("llx_rmsnorm_bwd");

@@ -24,7 +24,7 @@ SIGNATURES: dict[str, tuple] = {
     "llx_device_info": (c_int, [c_int, c_char_p, c_int]),
     "llx_rmsnorm_fwd": (c_int, [_P, _P, _P, _P, _L, _L, _F, _P]),
     "llx_rmsnorm_bwd_workspace_bytes": (c_int64, [_L, _L]),
-    "llx_rmsnorm_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _I, _P, _L, _L, _P]),
+    "llx_rmsnorm_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _I, _P, _P, _L, _L, _P]),
     "llx_debug_attn_fwd_occupancy": (c_int, []),
     "llx_attn_flags_bytes": (c_int64, [_L, _L]),
     "llx_attn_tile_flags": (c_int, [_P, _P, _P, _L, _L, _P]),
@@ -50,6 +50,7 @@ SIGNATURES: dict[str, tuple] = {
     "llx_gelu_bwd": (c_int, [_P, _L, _P, _L, _P, _L, _L, _L, _P]),
     "llx_col2im3": (c_int, [_P, _P, _L, _L, _L, _L, _P]),
     "llx_conv_w_reorder": (c_int, [_P, _P, _L, _L, _I, _P]),
+    "llx_lora_group_pack": (c_int, [_P, _P, _P, _P, _I, _L, _F, _P, _P, _P, _P, _P]),
     "llx_lora_pack": (c_int, [_P, _L, _P, _L, _L, _L, _L, _L, _F, _I, _P]),
     "llx_pad64": (c_int, [_P, _L, _P, _L, _L, _F, _I, _P]),
     "llx_ce_workspace_bytes": (c_int64, [_L]),

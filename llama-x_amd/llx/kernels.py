@@ -51,8 +51,9 @@ def rmsnorm_fwd(x: Tensor, w: Tensor, eps: float) -> tuple[Tensor, Tensor]:
     return y.view(x.shape), rstd
 
 
-def rmsnorm_bwd(dy: Tensor, x: Tensor, w: Tensor, rstd: Tensor, need_dw: bool) -> tuple[Tensor, Optional[Tensor]]:
-    _chk_bf16(dy, x, w)
+def rmsnorm_bwd(dy: Tensor, x: Tensor, w: Tensor, rstd: Tensor, need_dw: bool, dres: Optional[Tensor] = None) -> tuple[Tensor, Optional[Tensor]]:
+    """dx (+ dres, the gradient coming around the residual connection, joined in the same pass), dw."""
+    _chk_bf16(dy, x, w, dres)
     x2, dy2 = _rows2d(x), _rows2d(dy)
     if dy2.stride(0) != dy2.shape[1]:
         dy2 = dy2.contiguous()
@@ -62,8 +63,11 @@ def rmsnorm_bwd(dy: Tensor, x: Tensor, w: Tensor, rstd: Tensor, need_dw: bool) -
     if need_dw:
         dw = torch.empty(dim, device=x.device, dtype=BF16)
         ws = torch.empty(_lib().llx_rmsnorm_bwd_workspace_bytes(rows, dim), device=x.device, dtype=torch.uint8)
-    L.check(_lib().llx_rmsnorm_bwd(L.ptr(dy2), L.ptr(x2), L.ptr(w), L.ptr(rstd), L.ptr(dx), L.ptr(dw), 0, L.ptr(ws), rows, dim, L.stream()),
-            "llx_rmsnorm_bwd")
+    if dres is not None:
+        dres = _rows2d(dres)
+        assert dres.shape == x2.shape and dres.stride(0) == dim
+    L.check(_lib().llx_rmsnorm_bwd(L.ptr(dy2), L.ptr(x2), L.ptr(w), L.ptr(rstd), L.ptr(dx), L.ptr(dw), 0, L.ptr(ws), L.ptr(dres), rows, dim,
+                                   L.stream()), "llx_rmsnorm_bwd")
     return dx.view(x.shape), dw
 
 
@@ -133,6 +137,35 @@ def lora_pack(x: Tensor, out: Tensor, row_off: int, col_off: int, scale_: float 
     assert row_off + rr <= out.shape[0] and col_off + cc <= out.shape[1], (x.shape, out.shape, row_off, col_off, transposed)
     L.check(_lib().llx_lora_pack(L.ptr(x), x.stride(0), L.ptr(out), out.stride(0), R, C, row_off, col_off, scale_, int(transposed), L.stream()),
             "llx_lora_pack")
+
+
+def lora_group_pack(lora_as: list, lora_bs: list, K_in: int, scale_: float):
+    """(a_cat [R,K], b2 [N,64], bT [R,N], a2t [K,64]) for the members' LoRA factors, built by one launch."""
+    import ctypes
+
+    nm = len(lora_as)
+    Ns = [b.shape[0] for b in lora_bs]
+    ranks = [a.shape[0] for a in lora_as]
+    for a, b in zip(lora_as, lora_bs):
+        _chk_bf16(a, b)
+        assert a.is_contiguous() and b.is_contiguous() and a.shape[1] == K_in and b.shape[1] == a.shape[0]
+    N, R = sum(Ns), sum(ranks)
+    dev = lora_as[0].device
+    buf = torch.empty(R * K_in + N * SK_PAD + R * N + K_in * SK_PAD, device=dev, dtype=BF16)
+    a_cat = buf[: R * K_in].view(R, K_in)
+    o = R * K_in
+    b2 = buf[o : o + N * SK_PAD].view(N, SK_PAD)
+    o += N * SK_PAD
+    bT = buf[o : o + R * N].view(R, N)
+    o += R * N
+    a2t = buf[o:].view(K_in, SK_PAD)
+    PA = (ctypes.c_void_p * nm)(*[a.data_ptr() for a in lora_as])
+    PB = (ctypes.c_void_p * nm)(*[b.data_ptr() for b in lora_bs])
+    NS = (ctypes.c_int64 * nm)(*Ns)
+    RS = (ctypes.c_int64 * nm)(*ranks)
+    L.check(_lib().llx_lora_group_pack(PA, PB, NS, RS, nm, K_in, scale_, L.ptr(a_cat), L.ptr(b2), L.ptr(bT), L.ptr(a2t), L.stream()),
+            "llx_lora_group_pack")
+    return a_cat, b2, bT, a2t
 
 
 def gemm_tn(a: Tensor, b: Tensor) -> Tensor:

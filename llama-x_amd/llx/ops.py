@@ -227,14 +227,12 @@ class GroupPlan:
             return [m.forward(x, out=out[:, o : o + n])[1] for m, o, n in zip(self.members, self.n_off, self.Ns)]
         t = b2 = None
         if self.R > 0:
-            a_cat = torch.empty(self.R, self.K, device=x.device, dtype=BF16)
-            b2 = torch.zeros(self.N, K.SK_PAD, device=x.device, dtype=BF16)
-            for m, ro, no in zip(self.members, self.r_off, self.n_off):
-                K.lora_pack(m.lora_a.detach(), a_cat, ro, 0)
-                K.lora_pack(m.lora_b.detach(), b2, no, ro, self.scale)
-            t = K.skinny_nt(x, a_cat)
+            # the four operand images (forward: a_cat, b2; backward: bT, a2t) come out of one launch and ride along in `saved`
+            a_cat, b2, bT, a2t = K.lora_group_pack([m.lora_a.detach() for m in self.members], [m.lora_b.detach() for m in self.members],
+                                                   self.K, self.scale)
+            t = (K.skinny_nt(x, a_cat), bT, a2t)
         if not self.int8:
-            K.gemm_nt(x, self.w_cat(), out=out, a2=t, b2=b2)
+            K.gemm_nt(x, self.w_cat(), out=out, a2=t[0] if t else None, b2=b2)
             return t
         if self.dynamic:
             from subclasses.int8 import quantize_int8_rowwise
@@ -245,7 +243,7 @@ class GroupPlan:
         else:
             y0 = K.gemm_nt(x, self.w_cat(), out=out if self.R == 0 else None, epilogue=K.EPI_COLSCALE, e=self.scale_cat())
         if self.R > 0:
-            K.gemm_nt(t, b2, out=out, epilogue=K.EPI_RESIDUAL, e=y0)
+            K.gemm_nt(t[0], b2, out=out, epilogue=K.EPI_RESIDUAL, e=y0)
         return t
 
     # ---- backward: returns (dx, grads aligned with tensors())
@@ -261,7 +259,7 @@ class GroupPlan:
                 dx = d if d is not None else dx
                 first = False
             return dx, grads
-        t = saved
+        t, bT, a2t = saved if saved is not None else (None, None, None)
         u = gA = gBt = None
         ni = iter(needs)
         need = []
@@ -269,9 +267,6 @@ class GroupPlan:
             cnt = len(m.tensors())
             need.append([next(ni) for _ in range(cnt)])
         if self.R > 0:
-            bT = torch.zeros(self.R, self.N, device=dy.device, dtype=BF16)
-            for m, ro, no in zip(self.members, self.r_off, self.n_off):
-                K.lora_pack(m.lora_b.detach(), bT, ro, no, 1.0, transposed=True)
             u = K.skinny_nt(dy, bT)  # [M,64]: column block i = dy_i @ B_i
             if any(nd[-2] for nd in need):
                 gA = torch.empty(self.R, self.K, device=dy.device, dtype=BF16)
@@ -290,13 +285,8 @@ class GroupPlan:
                 grads.append(gBt[no : no + n, ro : ro + m.rank].contiguous() if nd[j + 1] else None)
         dx = None
         if need_dx:
-            b2 = None
-            if self.R > 0:
-                b2 = torch.zeros(self.K, K.SK_PAD, device=dy.device, dtype=BF16)
-                for m, ro in zip(self.members, self.r_off):
-                    K.lora_pack(m.lora_a.detach(), b2, 0, ro, self.scale, transposed=True)
             g = K.scale(dy, colscale=self.scale_cat()) if self.int8 else dy  # (g * scale) rounded (subclasses/int8.py:127)
-            dx = K.gemm_nt(g, self.wt_cat(), out=dx_out, a2=u, b2=b2)
+            dx = K.gemm_nt(g, self.wt_cat(), out=dx_out, a2=u, b2=a2t if self.R > 0 else None)
         return dx, grads
 
 
@@ -445,11 +435,11 @@ class AttnBlockFn(Function):
         dx = dnw = None
         if meta.fuse_norm:
             if need_dxn:
-                dx, dnw = K.rmsnorm_bwd(dxn, x2, norm_w.detach(), rstd, ctx.needs_input_grad[2])
+                dx, dnw = K.rmsnorm_bwd(dxn, x2, norm_w.detach(), rstd, ctx.needs_input_grad[2], dy2 if (need_dx and meta.fuse_residual) else None)
         else:
             dx = dxn
-        if need_dx and meta.fuse_residual:
-            dx = K.add(dx, dy2)
+            if need_dx and meta.fuse_residual:
+                dx = K.add(dx, dy2)
         return (dx.view(B, S, D) if (dx is not None and need_dx) else None, None, dnw, None, *g_qkv, *g_o)
 
 
@@ -502,11 +492,11 @@ class MLPBlockFn(Function):
         dx = dnw = None
         if meta.fuse_norm:
             if need_dxn:
-                dx, dnw = K.rmsnorm_bwd(dxn, x2, norm_w.detach(), rstd, ctx.needs_input_grad[1])
+                dx, dnw = K.rmsnorm_bwd(dxn, x2, norm_w.detach(), rstd, ctx.needs_input_grad[1], dy2 if (need_dx and meta.fuse_residual) else None)
         else:
             dx = dxn
-        if need_dx and meta.fuse_residual:
-            dx = K.add(dx, dy2)
+            if need_dx and meta.fuse_residual:
+                dx = K.add(dx, dy2)
         return (dx.view(x.shape) if (dx is not None and need_dx) else None, dnw, None, *g_13, *g_2)
 
 

@@ -24,7 +24,7 @@ for rows, dim in [(7, 512), (4096, 4096), (384, 512), (33, 1024)]:
     dx = torch.empty_like(x)
     dw = torch.zeros(dim, device="cuda", dtype=torch.bfloat16)
     ws = torch.empty(lib.llx_rmsnorm_bwd_workspace_bytes(rows, dim), device="cuda", dtype=torch.uint8)
-    L.check(lib.llx_rmsnorm_bwd(L.ptr(dy), L.ptr(x), L.ptr(w), L.ptr(rstd), L.ptr(dx), L.ptr(dw), 0, L.ptr(ws), rows, dim, L.stream()), "rmsnorm_bwd")
+    L.check(lib.llx_rmsnorm_bwd(L.ptr(dy), L.ptr(x), L.ptr(w), L.ptr(rstd), L.ptr(dx), L.ptr(dw), 0, L.ptr(ws), None, rows, dim, L.stream()), "rmsnorm_bwd")
     xr = x.float().requires_grad_(); wr = w.float().requires_grad_()
     yr = xr * torch.rsqrt(xr.pow(2).mean(-1, keepdim=True) + 1e-5) * wr
     yr.backward(dy.float())
