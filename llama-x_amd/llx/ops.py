@@ -221,10 +221,17 @@ class GroupPlan:
         return _cached_multi(ss, "cat_scale", lambda: torch.cat(ss, 0) if len(ss) > 1 else ss[0])
 
     # ---- forward
-    def forward(self, x: Tensor, out: Tensor):
-        """out: [M, sum N] (row-strided view allowed).  Returns the saved LoRA intermediate t (or a per-member list)."""
+    def forward(self, x: Tensor, out: Optional[Tensor] = None, residual: Optional[Tensor] = None):
+        """out: [M, sum N] (row-strided view allowed; allocated when None).  ``residual`` [M, sum N] is added in the GEMM
+        epilogue (x + linear(..), modelling/llama.py:172-173).  Returns (out, saved) - saved feeds backward()."""
+        if out is None:
+            out = torch.empty(x.shape[0], self.N, device=x.device, dtype=BF16)
+        return out, self._forward(x, out, residual)
+
+    def _forward(self, x: Tensor, out: Tensor, residual: Optional[Tensor]):
         if not self.fused:
-            return [m.forward(x, out=out[:, o : o + n])[1] for m, o, n in zip(self.members, self.n_off, self.Ns)]
+            assert residual is None or len(self.members) == 1
+            return [m.forward(x, out=out[:, o : o + n], residual=residual)[1] for m, o, n in zip(self.members, self.n_off, self.Ns)]
         t = b2 = None
         if self.R > 0:
             # the four operand images (forward: a_cat, b2; backward: bT, a2t) come out of one launch and ride along in `saved`
@@ -232,18 +239,26 @@ class GroupPlan:
                                                    self.K, self.scale)
             t = (K.skinny_nt(x, a_cat), bT, a2t)
         if not self.int8:
-            K.gemm_nt(x, self.w_cat(), out=out, a2=t[0] if t else None, b2=b2)
+            if residual is not None:
+                K.gemm_nt(x, self.w_cat(), out=out, a2=t[0] if t else None, b2=b2, epilogue=K.EPI_RESIDUAL, e=residual)
+            else:
+                K.gemm_nt(x, self.w_cat(), out=out, a2=t[0] if t else None, b2=b2)
             return t
         if self.dynamic:
             from subclasses.int8 import quantize_int8_rowwise
             from subclasses.int8_mm import _launch as i8_gemm
 
             xi, xs = quantize_int8_rowwise(x)
-            y0 = i8_gemm(xi, self.w_cat(), xs, self.scale_cat(), out=out if self.R == 0 else None)
+            direct = self.R == 0 and residual is None
+            y0 = i8_gemm(xi, self.w_cat(), xs, self.scale_cat(), out=out if direct else None)
         else:
-            y0 = K.gemm_nt(x, self.w_cat(), out=out if self.R == 0 else None, epilogue=K.EPI_COLSCALE, e=self.scale_cat())
+            direct = self.R == 0 and residual is None
+            y0 = K.gemm_nt(x, self.w_cat(), out=out if direct else None, epilogue=K.EPI_COLSCALE, e=self.scale_cat())
+        # (x @ W8^T) * scale is rounded to bf16 first (subclasses/int8.py:118); adapter and residual are added after
         if self.R > 0:
-            K.gemm_nt(t[0], b2, out=out, epilogue=K.EPI_RESIDUAL, e=y0)
+            y0 = K.gemm_nt(t[0], b2, out=out if residual is None else None, epilogue=K.EPI_RESIDUAL, e=y0)
+        if residual is not None:
+            K.add(y0, residual, out=out)
         return t
 
     # ---- backward: returns (dx, grads aligned with tensors())
@@ -369,7 +384,7 @@ def rmsnorm(x: Tensor, w: Tensor, eps: float) -> Tensor:
 # attention residual branch:  [x +] wo( attn( rope(wq xn), rope(wk xn), wv xn ) ),  xn = [rmsnorm(x)]
 # =================================================================================================
 class AttnBlockMeta:
-    def __init__(self, qkv: GroupPlan, wo: LinearPlan, num_heads, num_kv_heads, head_dim, mask, eps, fuse_norm, fuse_residual):
+    def __init__(self, qkv: GroupPlan, wo: GroupPlan, num_heads, num_kv_heads, head_dim, mask, eps, fuse_norm, fuse_residual):
         self.qkv, self.wo = qkv, wo
         self.H, self.KVH, self.hd = num_heads, num_kv_heads, head_dim
         self.mask, self.eps = mask, eps
@@ -389,7 +404,7 @@ class AttnBlockFn(Function):
             xn, rstd = x2, None
         W = (H + 2 * KVH) * hd
         qkv = torch.empty(B * S, W, device=x.device, dtype=BF16)
-        tqkv = meta.qkv.forward(xn, qkv)
+        _, tqkv = meta.qkv.forward(xn, qkv)
         qkv3 = qkv.view(B, S, W)
         K.rope_(qkv3, rope, H + KVH)
         q = qkv3[..., : H * hd].unflatten(-1, (H, hd))
@@ -397,7 +412,7 @@ class AttnBlockFn(Function):
         v = qkv3[..., (H + KVH) * hd :].unflatten(-1, (KVH, hd))
         o, lse = K.attn_fwd(q, k, v, meta.mask)
         o2 = o.view(B * S, H * hd)
-        y, to = meta.wo.forward(o2, residual=x2 if meta.fuse_residual else None)
+        y, to = meta.wo.forward(o2, None, x2 if meta.fuse_residual else None)
         ctx.meta = meta
         ctx.save_for_backward(x, rope, norm_w)
         ctx.saved = (x2, xn, rstd, qkv3, o, lse, tqkv, to)
@@ -415,7 +430,7 @@ class AttnBlockFn(Function):
         n_qkv = len(meta.qkv.tensors())
         nqkv, no = needs[:n_qkv], needs[n_qkv:]
         # wo
-        do2, g_o = meta.wo.backward(dy2, o.view(B * S, H * hd), to, no)
+        do2, g_o = meta.wo.backward(dy2, o.view(B * S, H * hd), to, no, True)
         # attention
         W = (H + 2 * KVH) * hd
         dqkv = torch.empty(B, S, W, device=x.device, dtype=BF16)
@@ -447,7 +462,7 @@ class AttnBlockFn(Function):
 # MLP residual branch:  [x +] w2( silu(w1 xn) * w3 xn ),  xn = [rmsnorm(x)]
 # =================================================================================================
 class MLPBlockMeta:
-    def __init__(self, w13: GroupPlan, w2: LinearPlan, eps, fuse_norm, fuse_residual):
+    def __init__(self, w13: GroupPlan, w2: GroupPlan, eps, fuse_norm, fuse_residual):
         self.w13, self.w2 = w13, w2
         self.eps, self.fuse_norm, self.fuse_residual = eps, fuse_norm, fuse_residual
 
@@ -464,9 +479,9 @@ class MLPBlockFn(Function):
             xn, rstd = x2, None
         T, I = x2.shape[0], meta.w13.Ns[0]
         gu = torch.empty(T, 2 * I, device=x.device, dtype=BF16)
-        t13 = meta.w13.forward(xn, gu)
+        _, t13 = meta.w13.forward(xn, gu)
         h = K.swiglu_fwd(gu[:, :I], gu[:, I:])
-        y, t2 = meta.w2.forward(h, residual=x2 if meta.fuse_residual else None)
+        y, t2 = meta.w2.forward(h, None, x2 if meta.fuse_residual else None)
         ctx.meta = meta
         ctx.save_for_backward(x, norm_w)
         ctx.saved = (x2, xn, rstd, gu, h, t13, t2)
@@ -482,7 +497,7 @@ class MLPBlockFn(Function):
         needs = list(ctx.needs_input_grad[3:])
         n_13 = len(meta.w13.tensors())
         n13, n2 = needs[:n_13], needs[n_13:]
-        dh, g_2 = meta.w2.backward(dy2, h, t2, n2)
+        dh, g_2 = meta.w2.backward(dy2, h, t2, n2, True)
         dgu = torch.empty(T, 2 * I, device=x.device, dtype=BF16)
         K.swiglu_bwd(dh, gu[:, :I], gu[:, I:], dgu[:, :I], dgu[:, I:])
         need_dx = ctx.needs_input_grad[0]

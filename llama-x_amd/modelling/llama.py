@@ -161,7 +161,7 @@ class Attention(nn.Module):
             return self._run_dense(x, rope, norm, residual, mask, input_pos)
         if self.training and self.attn_dropout > 0.0:
             raise LlxError("attention dropout is not supported by the HIP attention kernel (reference default is 0.0)")
-        qkv, wo = ops.GroupPlan((self.wq, self.wk, self.wv)), ops.LinearPlan(self.wo)
+        qkv, wo = ops.GroupPlan((self.wq, self.wk, self.wv)), ops.GroupPlan((self.wo,))
         meta = ops.AttnBlockMeta(qkv, wo, self.num_heads, self.num_kv_heads, self.head_dim, _as_maskspec(block_mask),
                                  norm.eps if norm is not None else 0.0, norm is not None, residual)
         tensors = qkv.tensors() + wo.tensors()
@@ -190,7 +190,7 @@ class Attention(nn.Module):
             mask = torch.ones(L_, k.shape[2], dtype=torch.bool, device=x.device)
         o = K.attn_dense_fwd(q, k, v, mask)  # [B,H,L,hd]
         o2 = o.transpose(1, 2).reshape(B * L_, H * hd)
-        y, _ = ops.LinearPlan(self.wo).forward(o2, residual=K._rows2d(x.contiguous()) if residual else None)
+        y, _ = ops.GroupPlan((self.wo,)).forward(o2, None, K._rows2d(x.contiguous()) if residual else None)
         return y.view(B, L_, -1)
 
     def forward(self, x: Tensor, rope: Tensor, *, mask: Tensor | None = None, input_pos: Tensor | None = None,
@@ -207,7 +207,7 @@ class FeedForward(nn.Module):
         self.act = nn.SiLU()
 
     def _run(self, x: Tensor, norm: nn.Module | None, residual: bool) -> Tensor:
-        w13, w2 = ops.GroupPlan((self.w1, self.w3)), ops.LinearPlan(self.w2)
+        w13, w2 = ops.GroupPlan((self.w1, self.w3)), ops.GroupPlan((self.w2,))
         meta = ops.MLPBlockMeta(w13, w2, norm.eps if norm is not None else 0.0, norm is not None, residual)
         tensors = w13.tensors() + w2.tensors()
         return ops.MLPBlockFn.apply(x, norm.weight if norm is not None else None, meta, *tensors)
