@@ -299,34 +299,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv2_kernel(const AttnBwdArgs
   const int srow_in = lane >> 4, sslot = lane & 15;
   const bf16_t* qbase = a.q + (int64_t)b * a.q_sb + h * HD;
   const bf16_t* dbase = a.d_o + (int64_t)b * a.do_sb + h * HD;
-  uint32_t qoff[4], doff[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = i * 16 + wave * 4 + srow_in;
-    qoff[i] = (uint32_t)(((int64_t)row * a.q_ss + (sslot ^ dual_swz(row)) * 8) * 2);
-    doff[i] = (uint32_t)(((int64_t)row * a.do_ss + (sslot ^ dual_swz(row)) * 8) * 2);
-  }
   auto stage = [&](int buf, int qt) {
     char* sQ = smem + buf * DKV_STAGE_BYTES;
     char* sD = sQ + TILE_BYTES;
     char* sL = sD + TILE_BYTES;
-    if (qt * DKV_QT + DKV_QT <= a.S) {
-      const char* qtile = (const char*)(qbase + (int64_t)qt * DKV_QT * a.q_ss);
-      const char* dtile = (const char*)(dbase + (int64_t)qt * DKV_QT * a.do_ss);
+    // (addresses are recomputed per tile on purpose: hoisting them costs 8 VGPRs and pushes this kernel into scratch)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        __builtin_amdgcn_global_load_lds((gbl_void*)(qtile + qoff[i]), (lds_void*)(sQ + (i * 16 + wave * 4) * 256), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gbl_void*)(dtile + doff[i]), (lds_void*)(sD + (i * 16 + wave * 4) * 256), 16, 0, 0);
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int row = i * 16 + wave * 4 + srow_in;
-        const int qr = min(qt * DKV_QT + row, a.S - 1);
-        const int c = sslot ^ dual_swz(row);
-        __builtin_amdgcn_global_load_lds((gbl_void*)(qbase + (int64_t)qr * a.q_ss + c * 8), (lds_void*)(sQ + (i * 16 + wave * 4) * 256), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gbl_void*)(dbase + (int64_t)qr * a.do_ss + c * 8), (lds_void*)(sD + (i * 16 + wave * 4) * 256), 16, 0, 0);
-      }
+    for (int i = 0; i < 4; ++i) {
+      const int row = i * 16 + wave * 4 + srow_in;
+      const int qr = min(qt * DKV_QT + row, a.S - 1);
+      const int c = sslot ^ dual_swz(row);
+      __builtin_amdgcn_global_load_lds((gbl_void*)(qbase + (int64_t)qr * a.q_ss + c * 8), (lds_void*)(sQ + (i * 16 + wave * 4) * 256), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_void*)(dbase + (int64_t)qr * a.do_ss + c * 8), (lds_void*)(sD + (i * 16 + wave * 4) * 256), 16, 0, 0);
     }
     if (wave < 2) {  // wave 0: lse[64], wave 1: delta[64]
       const float* src = (wave == 0 ? a.lse : a.delta) + ((int64_t)b * a.H + h) * a.S + min(qt * DKV_QT + lane, a.S - 1);
