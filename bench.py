@@ -213,9 +213,9 @@ def main():
         torch.cuda.synchronize()
         tr = K.GEMM_TRACE
         K.GEMM_TRACE = None
-        tot_ms = sum(s.elapsed_time(e) for s, e, _ in tr)
-        tot_fl = sum(f for _, _, f in tr)
-        gemm_stats = {"launches": len(tr), "ms": tot_ms, "flops": tot_fl}
+        tot_ms = sum(s.elapsed_time(e) for s, e, _, _ in tr)
+        tot_fl = sum(f for _, _, f, _ in tr)
+        gemm_stats = {"launches": len(tr), "ms": tot_ms, "flops": tot_fl, "alg_bytes": sum(b for _, _, _, b in tr)}
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -235,8 +235,16 @@ def main():
             out["step_mfma_frac"] = round(gf * 1e9 * S / (ms_per_step * 1e-3) / 1e12 / BF16_DENSE_PEAK_TFLOPS, 4)
         if gemm_stats and gemm_stats["ms"] > 0:
             ach = gemm_stats["flops"] / (gemm_stats["ms"] * 1e-3) / 1e12
+            traffic = None  # HBM bytes per launch from the PMC passes committed under profiles/ (bench.py cannot run rocprofv3 on itself)
+            try:
+                with open(os.path.join(ROOT, "profiles", "r01_gemm_hbm_traffic.json")) as f:
+                    traffic = round(json.load(f)["hbm_bytes_per_launch"])
+            except (OSError, KeyError, ValueError):
+                pass
             out["roofline"] = {"bound": "mfma", "achieved": round(ach, 1), "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "frac": round(ach / BF16_DENSE_PEAK_TFLOPS, 4), "traffic": None, "kernel": "gemm_nt_kernel (bf16 MFMA GEMM)",
+                               "frac": round(ach / BF16_DENSE_PEAK_TFLOPS, 4), "traffic": traffic,
+                               "algorithmic_bytes_per_launch": round(gemm_stats["alg_bytes"] / max(1, gemm_stats["launches"])),
+                               "kernel": "gemm_nt_kernel (bf16 MFMA GEMM)",
                                "launches_per_step": gemm_stats["launches"], "avg_launch_us": round(gemm_stats["ms"] * 1e3 / max(1, gemm_stats["launches"]), 2),
                                "gemm_ms_per_step": round(gemm_stats["ms"], 2)}
         if world == 1 and not args.no_cpu_baseline:

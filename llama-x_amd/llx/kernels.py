@@ -103,7 +103,7 @@ def gemm_nt(a: Tensor, b: Tensor, *, out: Optional[Tensor] = None, a2: Optional[
                                     epilogue, L.ptr(e), lde, L.stream()), "llx_gemm_nt_bf16")
     if ev is not None:
         ev[1].record()
-        GEMM_TRACE.append((ev[0], ev[1], 2.0 * M * N * (K + K2)))
+        GEMM_TRACE.append((ev[0], ev[1], 2.0 * M * N * (K + K2), 2.0 * (M * (K + K2) + N * (K + K2) + M * N * (2 if epilogue == EPI_RESIDUAL else 1))))
     return out
 
 
