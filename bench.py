@@ -126,18 +126,24 @@ def main():
             raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    if world > 1:
+    if world > 1 or os.environ.get("LLX_FORCE_DP") == "1":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)  # "nccl" is RCCL on ROCm
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", device_id=device, rank=rank, world_size=world)  # "nccl" is RCCL on ROCm
 
     from llx import kernels as K
     from llx.dp import GradBuckets
 
     model, cfg = build_model(args.model, args.seq, args.rank, device)
     trainable = [p for p in model.parameters() if p.requires_grad]
-    buckets = GradBuckets(model, n_buckets=4)
-    use_graph = world == 1 and not args.no_graph
-    optim = torch.optim.AdamW(trainable, lr=1e-4, weight_decay=0.0, fused=True, capturable=use_graph)
+    force_dp = os.environ.get("LLX_FORCE_DP") == "1"  # rehearse the N>1 code path (flat buckets + RCCL) on one GPU
+    use_graph = not args.no_graph
+    dp = world > 1 or force_dp
+    # N>1: forward+backward replay from a hipGraph into flat gradient buckets, then ONE exchange of the 84 MB of trainable
+    # gradients (latency-bound on xGMI: ~1 ms) and the optimizer; --no-graph = eager launches with the exchange overlapped
+    # with backward from autograd hooks.  N=1: the optimizer step is captured too.
+    buckets = GradBuckets(model, n_buckets=4, force=force_dp, overlap=not use_graph)
+    optim = torch.optim.AdamW(trainable, lr=1e-4, weight_decay=0.0, fused=True, capturable=use_graph and not dp)
 
     S = args.seq
     gen = torch.Generator(device=device)
@@ -159,31 +165,46 @@ def main():
         return loss
 
     step = eager_step
+    launch_mode = "eager"
     if use_graph:
-        # The step has static shapes and no host decisions: capture forward + backward + AdamW once into a hipGraph and
-        # replay it, so that ~3000 kernel launches cost one host call (the batch is copied into static input buffers).
-        ids_buf, labels_buf = batch()
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(2):  # warm caches (transposed / concatenated weight images, LDS attributes) outside the capture
-                optim.zero_grad(set_to_none=True)
-                model(ids_buf, labels=labels_buf).backward()
-                optim.step()
-        torch.cuda.current_stream().wait_stream(side)
-        optim.zero_grad(set_to_none=True)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            static_loss = model(ids_buf, labels=labels_buf)
-            static_loss.backward()
-            optim.step()
+        try:
+            ids_buf, labels_buf = batch()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(2):  # warm caches (fused / transposed weight images, LDS attributes) outside the capture
+                    buckets.zero_grad()
+                    model(ids_buf, labels=labels_buf).backward()
+                    buckets.finish()
+                    optim.step()
+            torch.cuda.current_stream().wait_stream(side)
+            buckets.zero_grad()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                if dp:
+                    buckets.zero_grad()  # captured memset of the flat buckets (param.grad are views into them)
+                static_loss = model(ids_buf, labels=labels_buf)
+                static_loss.backward()
+                if not dp:
+                    optim.step()
 
-        def step():
-            ids, labels = batch()
-            ids_buf.copy_(ids)
-            labels_buf.copy_(labels)
-            graph.replay()
-            return static_loss
+            def step():
+                ids, labels = batch()
+                ids_buf.copy_(ids)
+                labels_buf.copy_(labels)
+                graph.replay()
+                if dp:
+                    buckets.finish()  # bucketed RCCL all-reduce of the flat gradient buffers
+                    optim.step()
+                return static_loss
+
+            launch_mode = "hipGraph replay (fwd+bwd" + ("+AdamW)" if not dp else "), then RCCL all-reduce + AdamW")
+        except Exception as exc:  # noqa: BLE001 - a capture problem must not cost the measurement: fall back to eager launches
+            print(f"[bench] graph capture failed ({type(exc).__name__}: {exc}); running eagerly", file=sys.stderr, flush=True)
+            torch.cuda.synchronize()
+            buckets = GradBuckets(model, n_buckets=4, force=force_dp, overlap=True)
+            optim = torch.optim.AdamW(trainable, lr=1e-4, weight_decay=0.0, fused=True)
+            step = eager_step
 
     def barrier():
         if world > 1:
@@ -207,8 +228,7 @@ def main():
     gemm_stats = None
     if rank == 0:
         K.GEMM_TRACE = []
-        if use_graph:
-            optim.zero_grad(set_to_none=True)
+        buckets.zero_grad()
         eager_step()  # traced eagerly (events between launches), same kernels and shapes as the timed steps
         torch.cuda.synchronize()
         tr = K.GEMM_TRACE
@@ -228,7 +248,7 @@ def main():
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"Llama-3.1-8B text-only LoRA r={args.rank} bf16, seq={S}, 1 sequence per GPU, causal mask, base+LM head frozen "
                                    "(BASELINE.json configs[1]); random-init weights at 8B dimensions" if args.model == "llama31_8b" else f"tiny plumbing config seq={S}",
-                       "global_batch_tokens": S * world, "seq_len": S, "parallelism": f"dp{world}", "loss": round(float(loss.detach()), 4), "launch": "hipGraph replay" if use_graph else "eager"},
+                       "global_batch_tokens": S * world, "seq_len": S, "parallelism": f"dp{world}", "loss": round(float(loss.detach()), 4), "launch": launch_mode},
         }
         gf = GF_PER_TOKEN.get(S)
         if gf and args.model == "llama31_8b":
@@ -250,7 +270,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(S, args.rank)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

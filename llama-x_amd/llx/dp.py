@@ -15,12 +15,16 @@ from torch import nn
 
 
 class GradBuckets:
-    def __init__(self, model: nn.Module, n_buckets: int = 4, process_group=None):
+    def __init__(self, model: nn.Module, n_buckets: int = 4, process_group=None, force: bool = False, overlap: bool = True):
+        """force: build the flat buckets even for a single replica (tests / rehearsal of the N>1 path on one GPU).
+        overlap: launch each bucket's all-reduce from backward hooks; False = exchange everything in finish()
+        (used when forward+backward replay from a captured hipGraph, where hooks do not run)."""
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.active = self.world > 1 or force
         params = [p for p in model.parameters() if p.requires_grad]
         self._params = params
-        if self.world == 1:
+        if not self.active:
             # single replica: nothing to exchange - leave .grad to autograd (no flat views, no accumulate-add kernels)
             self.buckets, self._handles, self._hooks, self.sync_enabled = [], [], [], True
             return
@@ -40,7 +44,7 @@ class GradBuckets:
             self.buckets.append(self._make(cur))
         self._handles = []
         self._hooks = []
-        if self.world > 1:
+        if overlap:
             for bi, b in enumerate(self.buckets):
                 for p in b["params"]:
                     self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(bi)))
@@ -60,26 +64,35 @@ class GradBuckets:
         def hook(param):
             b = self.buckets[bi]
             b["pending"] -= 1
-            if b["pending"] == 0 and self.sync_enabled:
+            if b["pending"] == 0 and self.sync_enabled and not (b["flat"].is_cuda and torch.cuda.is_current_stream_capturing()):
                 self._launch(b)
 
         return hook
 
     def _launch(self, b):
-        b["flat"].div_(self.world)  # pre-scale: sum of means = mean of sums, keeps bf16 range
-        self._handles.append(dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+        b["launched"] = True
+        if self.world > 1:
+            b["flat"].div_(self.world)  # pre-scale: sum of means = mean of sums, keeps bf16 range
+        if dist.is_initialized():
+            self._handles.append(dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
 
     def finish(self):
-        """Call after backward, before clip / optimizer.step: waits for the in-flight bucket all-reduces."""
+        """Call after backward, before clip / optimizer.step: exchanges whatever the hooks have not launched yet
+        (graph replay, parameters without a gradient this step) and waits for the in-flight bucket all-reduces."""
+        if self.active and self.sync_enabled:
+            for b in self.buckets:
+                if not b.get("launched"):
+                    self._launch(b)
         for h in self._handles:
             h.wait()
         self._handles.clear()
         for b in self.buckets:
             b["pending"] = len(b["params"])
+            b["launched"] = False
 
     def zero_grad(self):
         """Keep the views, zero the storage (optimizer.zero_grad(set_to_none=True) would drop the views)."""
-        if self.world == 1:
+        if not self.active:
             for p in self._params:
                 p.grad = None
             return

@@ -56,7 +56,16 @@ def _worker(rank, world, port, q):
     ref_model.zero_grad()
     (2 * ref_model(data).sum() / world).backward()
     ok2 = torch.allclose(acc, ref_model[0].weight.grad, atol=1e-5)
-    q.put((rank, bool(ok), bool(ok2), float(local_only.abs().sum())))
+    # step 3: no hooks (forward+backward replayed from a graph): finish() performs the whole exchange
+    m2 = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.Tanh(), torch.nn.Linear(16, 4), torch.nn.Linear(4, 1))
+    m2.load_state_dict(model.state_dict())
+    b2 = GradBuckets(m2, n_buckets=2, overlap=False)
+    m2(x).sum().backward()
+    b2.finish()
+    ref_model.zero_grad()
+    (ref_model(data).sum() / world).backward()
+    ok3 = all(torch.allclose(p.grad, dict(ref_model.named_parameters())[n].grad, atol=1e-6) for n, p in m2.named_parameters() if p.requires_grad)
+    q.put((rank, bool(ok), bool(ok2 and ok3), float(local_only.abs().sum())))
     dist.destroy_process_group()
 
 
@@ -67,7 +76,7 @@ def test_grad_buckets_world2():
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=120) for _ in range(world)]
+    res = [q.get(timeout=60) for _ in range(world)]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
