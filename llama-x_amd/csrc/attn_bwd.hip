@@ -91,8 +91,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnBwdArgs a
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nqb = (a.S + BQ - 1) / BQ, nkt = (a.S + BKV - 1) / BKV;
-  const int qb = nqb - 1 - blockIdx.x;
-  const int h = blockIdx.y, b = blockIdx.z;
+  const int qb = nqb - 1 - blockIdx.y;  // q-block = slow dispatch dimension: heaviest blocks of every head first
+  const int h = blockIdx.x, b = blockIdx.z;
   const int kvh = h / (a.H / a.KVH);
   const int r = lane & 31, hh = lane >> 5;
   const int qi = qb * BQ + wave * 32 + r;
@@ -490,8 +490,8 @@ extern "C" int llx_attn_bwd(const void* q, int64_t q_sb, int64_t q_ss, const voi
     hipLaunchKernelGGL(attn_dkv_reduce_kernel, dim3((unsigned)cdiv64(plane / 8, 256)), dim3(256), 0, stream, a, (const float*)part);
     LLX_LAUNCH_CHECK("llx_attn_bwd(dkv reduce)");
   }
-  if (a.flags) hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, dim3((unsigned)cdiv64(S, BQ), (unsigned)H, (unsigned)B), dim3(256), DQ_LDS_BYTES, stream, a);
-  else hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, dim3((unsigned)cdiv64(S, BQ), (unsigned)H, (unsigned)B), dim3(256), DQ_LDS_BYTES, stream, a);
+  if (a.flags) hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, dim3((unsigned)H, (unsigned)cdiv64(S, BQ), (unsigned)B), dim3(256), DQ_LDS_BYTES, stream, a);
+  else hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, dim3((unsigned)H, (unsigned)cdiv64(S, BQ), (unsigned)B), dim3(256), DQ_LDS_BYTES, stream, a);
   LLX_LAUNCH_CHECK("llx_attn_bwd(dq)");
   return LLX_OK;
 }

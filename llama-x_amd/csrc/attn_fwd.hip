@@ -36,17 +36,20 @@ struct AttnFwdArgs {
   const uint8_t* flags;   // [B, nqb, nkt] tile classes (0 skip, 1 partial, 2 full) or null => causal arithmetic
   int B, S, H, KVH;
   float scale_log2;       // softmax scale * log2(e)
+  unsigned long long* stamps;  // diagnostic (normally null): s_memtime stamps of block (x=0,h=0,b=0), wave 0
 };
 
 // GENERAL = false: pure causal (no doc_ids / prefix_len / tile flags) - the mask is index arithmetic only.
-template <bool GENERAL>
+template <bool GENERAL, bool STAMP = false>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nqb = (a.S + BQ - 1) / BQ, nkt = (a.S + BKV - 1) / BKV;
-  const int qb = nqb - 1 - blockIdx.x;  // heaviest (longest causal rows) first
-  const int h = blockIdx.y, b = blockIdx.z;
+  // grid = (heads, q-blocks, batch): the q-block index is the SLOW dispatch dimension, so that under a causal mask the
+  // heaviest blocks of EVERY head are handed out first (longest-processing-time order: no heavy straggler at the end)
+  const int qb = nqb - 1 - blockIdx.y;
+  const int h = blockIdx.x, b = blockIdx.z;
   const int kvh = h / (a.H / a.KVH);
   const int r = lane & 31, hh = lane >> 5;
   const int qi = qb * BQ + wave * 32 + r;  // this lane's query row
@@ -128,7 +131,19 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnFwdArgs a) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   int cur = 0;
+  int nst = 0;
+  auto stamp = [&]() {
+    if constexpr (STAMP) {
+      if (blockIdx.y == 0 && blockIdx.x == 0 && blockIdx.z == 0 && wave == 0 && nst < 512) {
+        unsigned long long tt;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tt) :: "memory");
+        if (lane == 0) a.stamps[nst] = tt;
+        ++nst;
+      }
+    }
+  };
   while (t < kt_end) {
+    stamp();  // 0: tile start
     const int tn = next_tile(t + 1);
     if (tn < kt_end) stage(cur ^ 1, tn);
     const char* sK = smem + cur * ATT_STAGE_BYTES;
@@ -140,13 +155,16 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnFwdArgs a) {
     for (int kb = 0; kb < 2; ++kb) {
       const int row = kb * 32 + r;
       const f32x16_t zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      // all 8 K fragments of the key block are in flight before the first MFMA: one LDS latency per block, not per MFMA
+      bf16x8_t kf[8];
 #pragma unroll
-      for (int ks = 0; ks < 8; ++ks) {
-        bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(sK + row * 256 + (((2 * ks + hh) ^ (row & 15)) << 4));
-        st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], ks == 0 ? zero : st[kb], 0, 0, 0);
-      }
+      for (int ks = 0; ks < 8; ++ks) kf[ks] = *reinterpret_cast<const bf16x8_t*>(sK + row * 256 + (((2 * ks + hh) ^ (row & 15)) << 4));
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], ks == 0 ? zero : st[kb], 0, 0, 0);
     }
 
+    stamp();  // 1: after QK^T
     // ---- mask, online softmax in log2 units (row statistics are per lane; the partner half-wave holds the other keys)
     const int cls = tile_class(t);
     float mx = -INFINITY;
@@ -192,6 +210,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnFwdArgs a) {
     l_run += rs;
     m_run = m_new;
 
+    stamp();  // 2: after softmax
     // ---- O^T += V^T.P^T : P^T k-step (kb, s) = accumulator regs 8s..8s+7; element j <-> key 32kb+16s+8(j>>2)+4hh+(j&3)
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
@@ -215,7 +234,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnFwdArgs a) {
         }
       }
 
+    stamp();  // 3: after PV
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    stamp();  // 4: after the load wait
     __syncthreads();
     cur ^= 1;
     t = tn;
@@ -298,6 +319,7 @@ extern "C" int llx_attn_fwd(const void* q, int64_t q_sb, int64_t q_ss, const voi
   a.doc_ids = doc_ids; a.prefix_len = prefix_len; a.flags = (doc_ids || prefix_len) ? (const uint8_t*)flags : nullptr;
   a.B = (int)B; a.S = (int)S; a.H = (int)H; a.KVH = (int)KVH;
   a.scale_log2 = scale * 1.4426950408889634f;
+  a.stamps = nullptr;
   static int lds_bytes = 0;
   if (!lds_bytes) {  // LLX_ATTN_LDS_PAD=1: experiment knob - ask for 96 KiB so that only ONE workgroup fits a CU
     const char* e = getenv("LLX_ATTN_LDS_PAD");
@@ -307,8 +329,8 @@ extern "C" int llx_attn_fwd(const void* q, int64_t q_sb, int64_t q_ss, const voi
       hipFuncSetAttribute((const void*)attn_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     }
   }
-  if (a.flags) hipLaunchKernelGGL(attn_fwd_kernel<true>, dim3((unsigned)cdiv64(S, BQ), (unsigned)H, (unsigned)B), dim3(256), lds_bytes, stream, a);
-  else hipLaunchKernelGGL(attn_fwd_kernel<false>, dim3((unsigned)cdiv64(S, BQ), (unsigned)H, (unsigned)B), dim3(256), lds_bytes, stream, a);
+  if (a.flags) hipLaunchKernelGGL(attn_fwd_kernel<true>, dim3((unsigned)H, (unsigned)cdiv64(S, BQ), (unsigned)B), dim3(256), lds_bytes, stream, a);
+  else hipLaunchKernelGGL(attn_fwd_kernel<false>, dim3((unsigned)H, (unsigned)cdiv64(S, BQ), (unsigned)B), dim3(256), lds_bytes, stream, a);
   LLX_LAUNCH_CHECK("llx_attn_fwd");
   return LLX_OK;
 }
@@ -320,4 +342,18 @@ extern "C" int llx_debug_attn_fwd_occupancy(void) {
   hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)attn_fwd_kernel<false>, 256, ATT_LDS_BYTES);
   if (e != hipSuccess) { llx_set_error("occupancy query: %s", hipGetErrorString(e)); return -1; }
   return n;
+}
+
+// Diagnostic build of the forward kernel with in-kernel s_memtime stamps (5 per key tile) for one wave; timing only.
+extern "C" int llx_debug_attn_fwd_stamps(const void* q, const void* k, const void* v, void* o, int64_t S, int64_t H, int64_t KVH,
+                                         unsigned long long* stamps, hipStream_t stream) {
+  AttnFwdArgs a;
+  a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.o = (bf16_t*)o; a.lse = nullptr;
+  a.q_ss = H * HD; a.q_sb = S * a.q_ss; a.k_ss = KVH * HD; a.k_sb = S * a.k_ss; a.v_ss = a.k_ss; a.v_sb = a.k_sb; a.o_ss = a.q_ss; a.o_sb = a.q_sb;
+  a.doc_ids = nullptr; a.prefix_len = nullptr; a.flags = nullptr; a.B = 1; a.S = (int)S; a.H = (int)H; a.KVH = (int)KVH;
+  a.scale_log2 = 0.08838834764f * 1.4426950408889634f; a.stamps = stamps;
+  hipFuncSetAttribute((const void*)attn_fwd_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS_BYTES);
+  hipLaunchKernelGGL((attn_fwd_kernel<false, true>), dim3((unsigned)H, (unsigned)cdiv64(S, BQ), 1), dim3(256), ATT_LDS_BYTES, stream, a);
+  LLX_LAUNCH_CHECK("llx_debug_attn_fwd_stamps");
+  return LLX_OK;
 }
