@@ -344,3 +344,51 @@ def test_kv_cache_prefill_and_decode(cuda):
 
     with pytest.raises(LlxError):
         layer(hid.to(cuda).requires_grad_(), model.rope[:384], mask=dense.to(cuda))
+
+
+def test_full_dimension_layer_parity(cuda):
+    """One TransformerLayer at the REAL Llama-3.1-8B dimensions (D 4096, 32/8 heads, I 14336, LoRA r=16, S=512) against the
+    oracle: exercises the production tile shapes (N = 6144 / 28672 fused groups, K-extension, GQA 4:1, 256-key causal tiles)."""
+    from modelling import apply_linear_adapter_
+    from modelling.llama import LlamaConfig, TransformerLayer, build_rope
+
+    cfg = O.LLAMA31_8B._replace(num_layers=1, max_seq_len=512)
+    S = 512
+    p = {k: v for k, v in O.init_params(cfg._replace(vocab_size=8)).items() if k.startswith("layers.0.")}
+    p.update(O.init_lora(cfg, 16))
+    pb, pf = bf16_params(p)
+    x = O.randn("x_full", (1, S, cfg.embed_dim), 0.5).bfloat16()
+    dy = O.randn("dy_full", (1, S, cfg.embed_dim), 0.1).bfloat16()
+    train = [k for k in pf if "lora_" in k or k.endswith("_norm.weight")]
+    pr = {k: (v.clone().requires_grad_() if k in train else v) for k, v in pf.items()}
+    xr = x.float().requires_grad_()
+    ref = O.layer(xr, pr, 0, cfg, O.rope_table(cfg)[:S], None, 1.0)
+    ref.backward(dy.float())
+
+    layer = TransformerLayer(LlamaConfig(**{f: getattr(cfg, f) for f in LlamaConfig._fields})).bfloat16()
+    layer.load_state_dict({k[len("layers.0."):]: v for k, v in pb.items() if "lora_" not in k})
+    apply_linear_adapter_(layer, "lora", rank=16, alpha=16.0)
+    with torch.no_grad():
+        for name, mod in layer.named_modules():
+            if f"layers.0.{name}.lora_a" in pb:
+                mod.lora_a.copy_(pb[f"layers.0.{name}.lora_a"])
+                mod.lora_b.copy_(pb[f"layers.0.{name}.lora_b"])
+    layer = layer.to(cuda)
+    for n, q in layer.named_parameters():
+        q.requires_grad_("lora_" in n or n.endswith("_norm.weight"))
+    rope = build_rope(LlamaConfig(**{f: getattr(cfg, f) for f in LlamaConfig._fields})).to(cuda)
+    xg = x.to(cuda).requires_grad_()
+    out = layer(xg, rope[:S])
+    out.backward(dy.to(cuda))
+    _close(out.float().cpu(), ref.detach(), 0.02, "layer output at 8B dims")
+    _close(xg.grad.float().cpu(), xr.grad, 0.04, "dx at 8B dims")
+    for name, q in layer.named_parameters():
+        if q.requires_grad:
+            _close(q.grad.float().cpu(), pr["layers.0." + name].grad, 0.05, name)
+    # determinism at full size: a second run is bit-identical (no atomics anywhere on the path)
+    xg2 = x.to(cuda).requires_grad_()
+    for q in layer.parameters():
+        q.grad = None
+    out2 = layer(xg2, rope[:S])
+    out2.backward(dy.to(cuda))
+    assert torch.equal(out2, out) and torch.equal(xg2.grad, xg.grad)
