@@ -50,68 +50,64 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const bf16_t* __restri
 }
 
 // ---------------------------------------------------------------- backward
-// Block per row-group: a 256-thread block walks `rows_per_block` rows; thread t owns columns
-// {c*2048 + t*8 .. +8}. dx is written per row; dw partial sums stay in registers and are
-// written once per block to dw_partial[blockIdx][dim] (fp32). A second kernel reduces them.
-//   xhat = x*rstd ; g = dy*w ; dx = rstd * (g - xhat * mean(g*xhat)) ; dw = sum_rows(dy*xhat)
+// One WAVE per row (no block-wide barriers): a 256-thread block = 4 waves walks `rows_per_block` rows, wave w taking rows
+// w, w+4, ...; lane l owns columns {c*512 + l*8 .. +8}.  dx is written per row; the per-lane dw partial sums stay in
+// registers, are combined across the 4 waves through LDS and written once per block to dw_partial[blockIdx][dim] (fp32).
+//   xhat = x*rstd ; g = dy*w ; dx = rstd * (g - xhat * mean(g*xhat)) [+ dres] ; dw = sum_rows(dy*xhat)
 template <int NCH>
 __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
                                                           const bf16_t* __restrict__ w, const float* __restrict__ rstd,
                                                           bf16_t* __restrict__ dx, float* __restrict__ dw_partial,
                                                           const bf16_t* __restrict__ dres, int64_t rows, int dim, int rows_per_block) {
-  __shared__ float red[16];
-  const int t = threadIdx.x;
+  extern __shared__ __attribute__((aligned(16))) float dwsh[];  // [dim] when dw is requested
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float wv[NCH][8];
   float dwacc[NCH][8];
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
-    const int col = c * 2048 + t * 8;
+    const int col = c * 512 + lane * 8;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) dwacc[c][e] = 0.f;
+    for (int e = 0; e < 8; ++e) { dwacc[c][e] = 0.f; wv[c][e] = 0.f; }
     if (col < dim) {
-      u32x4_t u = *reinterpret_cast<const u32x4_t*>(w + col);
+      const u32x4_t u = *reinterpret_cast<const u32x4_t*>(w + col);
 #pragma unroll
       for (int e = 0; e < 4; ++e) { wv[c][2 * e] = bflo(u[e]); wv[c][2 * e + 1] = bfhi(u[e]); }
-    } else {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) wv[c][e] = 0.f;
     }
   }
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
-  for (int64_t row = r0; row < r0 + rows_per_block && row < rows; ++row) {
+  for (int64_t row = r0 + wave; row < r0 + rows_per_block && row < rows; row += 4) {
     const float rs = rstd[row];
-    float xh[NCH][8], g[NCH][8];
+    u32x4_t xv[NCH], dv[NCH];
     float dot = 0.f;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
-      const int col = c * 2048 + t * 8;
+      const int col = c * 512 + lane * 8;
       if (col < dim) {
-        u32x4_t xv = *reinterpret_cast<const u32x4_t*>(x + row * dim + col);
-        u32x4_t dv = *reinterpret_cast<const u32x4_t*>(dy + row * dim + col);
+        xv[c] = *reinterpret_cast<const u32x4_t*>(x + row * dim + col);
+        dv[c] = *reinterpret_cast<const u32x4_t*>(dy + row * dim + col);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          float x0 = bflo(xv[e]) * rs, x1 = bfhi(xv[e]) * rs;
-          float d0 = bflo(dv[e]), d1 = bfhi(dv[e]);
-          xh[c][2 * e] = x0; xh[c][2 * e + 1] = x1;
+          const float x0 = bflo(xv[c][e]) * rs, x1 = bfhi(xv[c][e]) * rs;
+          const float d0 = bflo(dv[c][e]), d1 = bfhi(dv[c][e]);
           dwacc[c][2 * e] += d0 * x0; dwacc[c][2 * e + 1] += d1 * x1;
-          g[c][2 * e] = d0 * wv[c][2 * e]; g[c][2 * e + 1] = d1 * wv[c][2 * e + 1];
-          dot += g[c][2 * e] * x0 + g[c][2 * e + 1] * x1;
+          dot += d0 * wv[c][2 * e] * x0 + d1 * wv[c][2 * e + 1] * x1;
         }
       }
     }
-    dot = block_sum(dot, red);
+    dot = wave_sum(dot);
     const float m = dot / (float)dim;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
-      const int col = c * 2048 + t * 8;
+      const int col = c * 512 + lane * 8;
       if (col < dim) {
-        u32x4_t o;
         u32x4_t rv = {0u, 0u, 0u, 0u};
         if (dres) rv = *reinterpret_cast<const u32x4_t*>(dres + row * dim + col);
+        u32x4_t o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          float a = rs * (g[c][2 * e] - xh[c][2 * e] * m);
-          float b = rs * (g[c][2 * e + 1] - xh[c][2 * e + 1] * m);
+          const float x0 = bflo(xv[c][e]) * rs, x1 = bfhi(xv[c][e]) * rs;
+          float a = rs * (bflo(dv[c][e]) * wv[c][2 * e] - x0 * m);
+          float b = rs * (bfhi(dv[c][e]) * wv[c][2 * e + 1] - x1 * m);
           if (dres) {  // gradient of the residual branch joins here: bf16(dx) + dres, rounded as the eager add would
             a = bf2f(f2bf(a)) + bflo(rv[e]);
             b = bf2f(f2bf(b)) + bfhi(rv[e]);
@@ -123,15 +119,21 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restri
     }
   }
   if (dw_partial) {
+    for (int wsel = 0; wsel < 4; ++wsel) {  // waves add their partial sums into LDS one after the other
+      if (wave == wsel) {
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-      const int col = c * 2048 + t * 8;
-      if (col < dim) {
-        float* p = dw_partial + (int64_t)blockIdx.x * dim + col;
-        *reinterpret_cast<f32x4_t*>(p) = f32x4_t{dwacc[c][0], dwacc[c][1], dwacc[c][2], dwacc[c][3]};
-        *reinterpret_cast<f32x4_t*>(p + 4) = f32x4_t{dwacc[c][4], dwacc[c][5], dwacc[c][6], dwacc[c][7]};
+        for (int c = 0; c < NCH; ++c) {
+          const int col = c * 512 + lane * 8;
+          if (col < dim) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dwsh[col + e] = (wsel == 0 ? 0.f : dwsh[col + e]) + dwacc[c][e];
+          }
+        }
       }
+      __syncthreads();
     }
+    for (int col = threadIdx.x * 4; col < dim; col += 256 * 4)
+      *reinterpret_cast<f32x4_t*>(dw_partial + (int64_t)blockIdx.x * dim + col) = *reinterpret_cast<const f32x4_t*>(dwsh + col);
   }
 }
 
@@ -184,10 +186,11 @@ extern "C" int llx_rmsnorm_bwd(const void* dy, const void* x, const void* w, con
   if (rows == 0) return LLX_OK;
   const int rpb = 16;
   const int nblk = (int)cdiv64(rows, rpb);
-  const int nch = (int)cdiv64(dim, 2048);
+  const int nch = (int)cdiv64(dim, 512);
   float* part = dw ? (float*)workspace : nullptr;
-#define L(N) hipLaunchKernelGGL(rmsnorm_bwd_kernel<N>, dim3(nblk), dim3(256), 0, stream, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)w, rstd, (bf16_t*)dx, part, (const bf16_t*)dres, rows, (int)dim, rpb)
-  if (nch <= 1) L(1); else if (nch <= 2) L(2); else L(4);
+  const size_t lds = dw ? (size_t)dim * 4 : 0;
+#define L(N) hipLaunchKernelGGL(rmsnorm_bwd_kernel<N>, dim3(nblk), dim3(256), lds, stream, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)w, rstd, (bf16_t*)dx, part, (const bf16_t*)dres, rows, (int)dim, rpb)
+  if (nch <= 1) L(1); else if (nch <= 2) L(2); else if (nch <= 4) L(4); else if (nch <= 8) L(8); else L(16);
 #undef L
   LLX_LAUNCH_CHECK("llx_rmsnorm_bwd");
   if (dw) {
