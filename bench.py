@@ -26,8 +26,9 @@ GF_PER_TOKEN = {4096: 34.0, 8192: 37.8}
 BF16_DENSE_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
 
 
-def build_model(cfg_name: str, seq: int, rank: int, device):
-    from modelling import Llama, LlamaConfig, apply_linear_adapter_
+def build_model(cfg_name: str, seq: int, rank: int, device, config: str = "text"):
+    from modelling import Llama, LlamaAudio, LlamaConfig, apply_linear_adapter_
+    from subclasses import quantize_linear_
 
     if cfg_name == "llama31_8b":
         cfg = LlamaConfig(embed_dim=4096, num_layers=32, head_dim=128, num_heads=32, num_kv_heads=8, intermediate_dim=14336,
@@ -36,7 +37,7 @@ def build_model(cfg_name: str, seq: int, rank: int, device):
         cfg = LlamaConfig(embed_dim=512, num_layers=2, head_dim=128, num_heads=4, num_kv_heads=1, intermediate_dim=1792,
                           max_seq_len=seq, vocab_size=1024, rope_base=500_000, is_llama3_1=True)
     with torch.device("meta"):
-        model = Llama(cfg)
+        model = (LlamaAudio if config == "audio" else Llama)(cfg)
     model = model.to(torch.bfloat16).to_empty(device=device)
     g = torch.Generator(device=device)
     g.manual_seed(1234)
@@ -48,8 +49,12 @@ def build_model(cfg_name: str, seq: int, rank: int, device):
                 p.normal_(0.0, 0.02, generator=g)
     model.build_cache()
     model.rope = model.rope.to(device)
+    if config == "audio":
+        model.melspec = model.melspec.to(device)
     for n, p in model.named_parameters():
-        p.requires_grad_(False)
+        p.requires_grad_(n.startswith("audio_embed"))
+    if config == "int8":
+        quantize_linear_(model.layers, "int8", dynamic_int8_act=True)  # quantise, then adapt (train_metamathqa.py:178-179)
     apply_linear_adapter_(model.layers, "lora", rank=rank, alpha=float(rank))
     with torch.no_grad():
         for n, p in model.named_parameters():
@@ -114,6 +119,9 @@ def main():
     ap.add_argument("--seq", type=int, default=4096)
     ap.add_argument("--rank", type=int, default=16)
     ap.add_argument("--model", default="llama31_8b", choices=["llama31_8b", "tiny"])
+    ap.add_argument("--config", default="text", choices=["text", "int8", "audio"],
+                    help="text: BASELINE configs[1] (headline); int8: configs[3] per-GPU (INT8 frozen base, dynamic int8 activations, i8 MFMA) ; "
+                         "audio: configs[2] (mel+Conv1D prefix of seq/2 audio tokens + seq/2 text tokens, prefix-LM mask, audio_embed trainable)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a captured hipGraph (single GPU)")
     args = ap.parse_args()
@@ -134,7 +142,7 @@ def main():
     from llx import kernels as K
     from llx.dp import GradBuckets
 
-    model, cfg = build_model(args.model, args.seq, args.rank, device)
+    model, cfg = build_model(args.model, args.seq, args.rank, device, args.config)
     trainable = [p for p in model.parameters() if p.requires_grad]
     force_dp = os.environ.get("LLX_FORCE_DP") == "1"  # rehearse the N>1 code path (flat buckets + RCCL) on one GPU
     use_graph = not args.no_graph
@@ -148,16 +156,29 @@ def main():
     S = args.seq
     gen = torch.Generator(device=device)
     gen.manual_seed(rank)  # rank-distinct data streams
+    audio_cfg = args.config == "audio"
+    St = S // 2 if audio_cfg else S  # audio: S/2 audio tokens (S/2 * 320 samples) + S/2 text tokens
+    if audio_cfg:
+        from modelling.llama import MaskSpec
+
+        audio_buf = (torch.rand(1, St * 320, device=device, generator=gen) - 0.5) * 0.2
+        prefix_mask = MaskSpec(prefix_len=torch.tensor([St], device=device, dtype=torch.int32))
+
     def batch():
-        ids = torch.randint(0, cfg.vocab_size, (1, S), device=device, generator=gen)
+        ids = torch.randint(0, cfg.vocab_size, (1, St), device=device, generator=gen)
         labels = torch.roll(ids, -1, 1)
-        labels[:, : S // 4] = -100
+        labels[:, : St // 4] = -100
         labels[:, -1] = -100
         return ids, labels
 
+    def run_model(ids, labels):
+        if audio_cfg:
+            return model(audio_buf, ids, labels=labels, block_mask=prefix_mask)
+        return model(ids, labels=labels)
+
     def eager_step():
         ids, labels = batch()
-        loss = model(ids, labels=labels)
+        loss = run_model(ids, labels)
         loss.backward()
         buckets.finish()
         optim.step()
@@ -174,7 +195,7 @@ def main():
             with torch.cuda.stream(side):
                 for _ in range(2):  # warm caches (fused / transposed weight images, LDS attributes) outside the capture
                     buckets.zero_grad()
-                    model(ids_buf, labels=labels_buf).backward()
+                    run_model(ids_buf, labels_buf).backward()
                     buckets.finish()
                     optim.step()
             torch.cuda.current_stream().wait_stream(side)
@@ -183,7 +204,7 @@ def main():
             with torch.cuda.graph(graph):
                 if dp:
                     buckets.zero_grad()  # captured memset of the flat buckets (param.grad are views into them)
-                static_loss = model(ids_buf, labels=labels_buf)
+                static_loss = run_model(ids_buf, labels_buf)
                 static_loss.backward()
                 if not dp:
                     optim.step()
@@ -214,11 +235,15 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         loss = step()
+        marks[i + 1].record()
     barrier()
     elapsed = time.perf_counter() - t0
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -244,14 +269,21 @@ def main():
         out = {
             "metric": "train tokens/sec Llama-3.1-8B seq4096 at 1/2/4/8 MI355X; p50 step ms",
             "value": round(value, 1), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(ms_per_step, 2),
+            "p50_step_ms": round(per_step[len(per_step) // 2], 2), "p10_step_ms": round(per_step[len(per_step) // 10], 2),
+            "p90_step_ms": round(per_step[min(len(per_step) - 1, (9 * len(per_step)) // 10)], 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"Llama-3.1-8B text-only LoRA r={args.rank} bf16, seq={S}, 1 sequence per GPU, causal mask, base+LM head frozen "
-                                   "(BASELINE.json configs[1]); random-init weights at 8B dimensions" if args.model == "llama31_8b" else f"tiny plumbing config seq={S}",
+            "config": {"workload": ({"text": f"Llama-3.1-8B text-only LoRA r={args.rank} bf16, seq={S}, 1 sequence per GPU, causal mask, base+LM head frozen "
+                                             "(BASELINE.json configs[1]); random-init weights at 8B dimensions",
+                                     "int8": f"Llama-3.1-8B INT8 frozen base (dynamic int8 activations, i8 MFMA int8_mm_dequant) + bf16 LoRA r={args.rank}, seq={S}, "
+                                             "1 sequence per GPU (BASELINE.json configs[3] per-GPU workload)",
+                                     "audio": f"Llama-3.1-8B + mel/Conv1D audio prefix ({St} audio tokens from {St * 320} samples) + {St} text tokens, prefix-LM mask, "
+                                              f"LoRA r={args.rank} + trainable audio_embed (BASELINE.json configs[2])"}[args.config]
+                                    if args.model == "llama31_8b" else f"tiny plumbing config seq={S} ({args.config})"),
                        "global_batch_tokens": S * world, "seq_len": S, "parallelism": f"dp{world}", "loss": round(float(loss.detach()), 4), "launch": launch_mode},
         }
         gf = GF_PER_TOKEN.get(S)
-        if gf and args.model == "llama31_8b":
+        if gf and args.model == "llama31_8b" and args.config == "text":
             out["step_mfma_frac"] = round(gf * 1e9 * S / (ms_per_step * 1e-3) / 1e12 / BF16_DENSE_PEAK_TFLOPS, 4)
         if gemm_stats and gemm_stats["ms"] > 0:
             ach = gemm_stats["flops"] / (gemm_stats["ms"] * 1e-3) / 1e12
