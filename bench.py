@@ -249,13 +249,15 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
 
-    # ---- live roofline of the dominant kernel (the bf16 MFMA GEMM): one more step with HIP events around every launch
+    # ---- live roofline of the dominant kernel (the bf16 MFMA GEMM): one more step with HIP events around every launch.
+    # Every rank runs the step (it contains the gradient exchange); only rank 0 records events.
     gemm_stats = None
     if rank == 0:
         K.GEMM_TRACE = []
-        buckets.zero_grad()
-        eager_step()  # traced eagerly (events between launches), same kernels and shapes as the timed steps
-        torch.cuda.synchronize()
+    buckets.zero_grad()
+    eager_step()  # traced eagerly (events between launches), same kernels and shapes as the timed steps
+    torch.cuda.synchronize()
+    if rank == 0:
         tr = K.GEMM_TRACE
         K.GEMM_TRACE = None
         tot_ms = sum(s.elapsed_time(e) for s, e, _, _ in tr)
@@ -301,9 +303,14 @@ def main():
                                "gemm_ms_per_step": round(gemm_stats["ms"], 2)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(S, args.rank)
-        print(json.dumps(out), flush=True)
+        result_line = json.dumps(out)
+    else:
+        result_line = None
     if dist.is_initialized():
         dist.destroy_process_group()
+    if result_line is not None:
+        sys.stdout.flush()
+        print(result_line, flush=True)  # the ONE JSON line, last thing on stdout
 
 
 if __name__ == "__main__":
