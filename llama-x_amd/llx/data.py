@@ -108,3 +108,56 @@ class LRScheduler:
                 group["lr"].fill_(lr)
             else:
                 group["lr"] = lr
+
+
+class DevicePrefetcher:
+    """Host iterator -> device batches with the H2D copy of batch i+1 overlapped with the compute of batch i.
+
+    The reference moves every batch with a blocking ``.cuda()`` inside the iterator (train_metamathqa.py:48,65,71) or from
+    DataLoader workers with pin_memory (train_librispeech.py:184-192).  Here tensors are staged in pinned host memory and
+    copied on a side HIP stream; ``next()`` makes the compute stream wait on the copy event only.  Non-tensor items (None,
+    MaskSpec) pass through; a MaskSpec's metadata is moved with the batch.
+    """
+
+    def __init__(self, it, device, depth: int = 2):
+        self.it, self.device, self.depth = iter(it), torch.device(device), depth
+        self.stream = torch.cuda.Stream(device=self.device)
+        self.queue = []
+        for _ in range(depth):
+            self._push()
+
+    def _to_device(self, item):
+        from .kernels import MaskSpec
+
+        if isinstance(item, Tensor):
+            host = item if item.is_pinned() else item.pin_memory()
+            return host.to(self.device, non_blocking=True)
+        if isinstance(item, MaskSpec):
+            return MaskSpec(None if item.doc_ids is None else self._to_device(item.doc_ids.to(torch.int32)),
+                            None if item.prefix_len is None else self._to_device(torch.as_tensor(item.prefix_len, dtype=torch.int32)))
+        return item
+
+    def _push(self):
+        try:
+            batch = next(self.it)
+        except StopIteration:
+            return
+        with torch.cuda.stream(self.stream):
+            moved = tuple(self._to_device(x) for x in batch)
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        self.queue.append((moved, ev))
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        if not self.queue:
+            raise StopIteration
+        moved, ev = self.queue.pop(0)
+        torch.cuda.current_stream(self.device).wait_event(ev)
+        for x in moved:
+            if isinstance(x, Tensor):
+                x.record_stream(torch.cuda.current_stream(self.device))
+        self._push()
+        return moved

@@ -392,3 +392,23 @@ def test_full_dimension_layer_parity(cuda):
     out2 = layer(xg2, rope[:S])
     out2.backward(dy.to(cuda))
     assert torch.equal(out2, out) and torch.equal(xg2.grad, xg.grad)
+
+
+def test_packed_iterator_with_prefetch_trains(cuda):
+    """N3: the document-mask packer (llx.data, bit-exact with the oracle's restatement of train_metamathqa.py:51-83) feeding the
+    model through the pinned-memory prefetcher; losses equal the oracle's on the same packed buffers."""
+    from llx import data as D
+
+    pb, pf = bf16_params(O.init_params(CFG))
+    docs = [O.randint(f"doc{i}", (n,), 1, CFG.vocab_size) for i, n in enumerate((90, 130, 64, 200, 17, 150, 99, 260, 40))]
+    gen = torch.Generator().manual_seed(0)
+    it = D.document_mask_iterator(list(docs), 384, generator=gen)
+    host_batches = [next(it) for _ in range(2)]
+    model = build_model(CFG, pb, cuda)
+    pre = D.DevicePrefetcher(iter(host_batches), cuda)
+    for (inputs, labels, ms), (hi, hl, hm) in zip(pre, host_batches):
+        assert inputs.is_cuda and torch.equal(inputs.cpu(), hi)
+        with torch.no_grad():
+            loss = model(inputs, labels=labels, block_mask=ms)
+        ref = O.llama_forward(hi, pf, CFG, mask=O.document_mask(hm.doc_ids.cpu().long().view(-1))[None, None], labels=hl)
+        assert abs(loss.item() - ref.item()) < 3e-3 * max(1.0, abs(ref.item())), (loss.item(), ref.item())
