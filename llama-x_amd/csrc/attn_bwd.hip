@@ -14,6 +14,7 @@
 //               dK^T += Q^T.dS with P/dS from the accumulator registers and Q^T/dO^T by transposed LDS reads.
 // LDS images read both by rows and transposed use the dual-use swizzle  slot = chunk ^ (((row&3)<<2) | ((row>>2)&3)).
 #include "common.h"
+#include <cstdlib>
 
 #define HD 128
 #define BQ 128
@@ -26,6 +27,7 @@ typedef __attribute__((address_space(3))) s16x4_t lds_s16x4;
 typedef __attribute__((ext_vector_type(8))) short s16x8_t;
 
 __device__ __forceinline__ int dual_swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+__device__ __forceinline__ uint32_t dual_swz(uint32_t row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
 
 // A-operand fragment (32 rows x 16 k) read TRANSPOSED from a dual-use [rows][128] bf16 LDS image:
 // returns X^T[col = 32*db + (lane&31)][row = row0 + 8*(j>>2) + 4*hh + (j&3)], j = 0..7  (row0 multiple of 16).
@@ -406,6 +408,212 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv2_kernel(const AttnBwdArgs
   }
 }
 
+// ---- dkv3: the same algorithm as dkv2 with every LDS address written as  (lane constant ^ small constant) + immediate.
+// hipcc cannot see that the swizzled addresses of the 8 k-steps / 4 d-blocks differ by an XOR of the low byte, so in dkv2 it
+// keeps ~30 address registers live, spills them (124 B of scratch) and reloads them behind `s_waitcnt vmcnt(0)` - which also
+// waits for the NEXT tile's LDS-DMA and turns the prefetch synchronous.  LDS map (bytes, 256-aligned base):
+//   stage s: Q image s*0x8000, dO image s*0x8000 + 0x4000;  lse[64] at 0x10000 + s*512, delta[64] at 0x10100 + s*512.
+typedef __attribute__((address_space(3))) char lds_char;
+typedef __attribute__((address_space(3))) bf16x8_t lds_bf16x8;
+typedef __attribute__((address_space(3))) f32x4_t lds_f32x4;
+#define DKV3_LDS_BYTES (0x10000 + 1024)
+
+// a ^ c issued where it is written: as plain C++ hipcc computes all the XORed addresses of a tile up front and keeps them live
+__device__ __forceinline__ uint32_t xor_imm(uint32_t a, int c) {
+  if (c == 0) return a;
+  uint32_t r;
+  asm volatile("v_xor_b32 %0, %1, %2" : "=v"(r) : "n"(c), "v"(a));
+  return r;
+}
+
+template <bool GENERAL>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv3_kernel(const AttnBwdArgs a, float* __restrict__ part) {
+  extern __shared__ __attribute__((aligned(256))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nqb = (a.S + BQ - 1) / BQ, nkt = (a.S + BKV - 1) / BKV;
+  const int nqt = (a.S + DKV_QT - 1) / DKV_QT;
+  const int G = a.H / a.KVH;
+  int id = blockIdx.x;
+  const int per_kb = a.B * a.KVH * G;
+  const int kblk = id / per_kb;
+  id -= kblk * per_kb;
+  const int b = id / (a.KVH * G);
+  id -= b * (a.KVH * G);
+  const int kvh = id / G, g = id % G;
+  const int h = kvh * G + g;
+  const int r = lane & 31, hh = lane >> 5;
+  const int key = kblk * DKV2_KEYS + wave * 32 + r;
+  const int krow = min(key, a.S - 1);
+  const int my_kt = 2 * kblk + (wave >> 1);
+
+  bf16x8_t kf[8], vf[8];
+  {
+    const bf16_t* kp = a.k + (int64_t)b * a.k_sb + (int64_t)krow * a.k_ss + kvh * HD + 8 * hh;
+    const bf16_t* vp = a.v + (int64_t)b * a.v_sb + (int64_t)krow * a.v_ss + kvh * HD + 8 * hh;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      kf[ks] = *reinterpret_cast<const bf16x8_t*>(kp + 16 * ks);
+      vf[ks] = *reinterpret_cast<const bf16x8_t*>(vp + 16 * ks);
+    }
+  }
+  const int* docrow = (GENERAL && a.doc_ids) ? a.doc_ids + (int64_t)b * a.S : nullptr;
+  const int key_doc = docrow ? docrow[krow] : 0;
+  const int my_prefix = (GENERAL && a.prefix_len) ? a.prefix_len[b] : 0;
+
+  const int qt_first = GENERAL ? 0 : (kblk * DKV2_KEYS) / DKV_QT;
+  auto block_class = [&](int qt, int kt) -> int {
+    if (kt >= nkt) return 0;
+    if constexpr (GENERAL) return a.flags[((int64_t)b * nqb + (qt >> 1)) * nkt + kt];
+    const int q_lo = qt * DKV_QT, q_hi = q_lo + DKV_QT - 1, k_lo = kt * BKV, k_hi = k_lo + BKV - 1;
+    if (k_lo > q_hi) return 0;
+    return (k_hi <= q_lo) ? 2 : 1;
+  };
+  auto next_qt = [&](int qt) {
+    while (qt < nqt && !(qt >= qt_first && (block_class(qt, 2 * kblk) != 0 || block_class(qt, 2 * kblk + 1) != 0))) ++qt;
+    return qt;
+  };
+
+  const uint32_t sbase = (uint32_t)(uintptr_t)(lds_char*)smem;
+
+  // staging: thread -> rows i*16 + wave*4 + (lane>>4), 16-byte slot lane&15; the swizzle of those rows does not depend on i.
+  // Lane offsets are rebuilt from a fresh lane id per call for the same reason as the read constants.
+  const char* qbase = (const char*)(a.q + (int64_t)b * a.q_sb + h * HD);
+  const char* dbase = (const char*)(a.d_o + (int64_t)b * a.do_sb + h * HD);
+  const float* lbase = (wave == 0 ? a.lse : a.delta) + ((int64_t)b * a.H + h) * a.S;
+  auto stage = [&](int buf, int qt) {
+    uint32_t ln;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
+    const uint32_t srow = wave * 4 + (ln >> 4);
+    const uint32_t sc = (ln & 15) ^ dual_swz(srow);
+    lds_char* sQ = (lds_char*)smem + buf * 0x8000 + wave * 1024;
+    if (qt * DKV_QT + DKV_QT <= a.S) {
+      const uint32_t q_lane = (srow * (uint32_t)a.q_ss + sc * 8) * 2, d_lane = (srow * (uint32_t)a.do_ss + sc * 8) * 2;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const char* qu = qbase + (int64_t)(qt * DKV_QT + i * 16) * a.q_ss * 2;   // wave-uniform
+        const char* du = dbase + (int64_t)(qt * DKV_QT + i * 16) * a.do_ss * 2;
+        __builtin_amdgcn_global_load_lds((gbl_void*)(qu + q_lane), (lds_void*)(sQ + i * 4096), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_void*)(du + d_lane), (lds_void*)(sQ + 0x4000 + i * 4096), 16, 0, 0);
+      }
+    } else {  // ragged last tile: clamp the row per lane
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int qr = min(qt * DKV_QT + i * 16 + (int)srow, a.S - 1);
+        __builtin_amdgcn_global_load_lds((gbl_void*)(qbase + ((int64_t)qr * a.q_ss + sc * 8) * 2), (lds_void*)(sQ + i * 4096), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_void*)(dbase + ((int64_t)qr * a.do_ss + sc * 8) * 2), (lds_void*)(sQ + 0x4000 + i * 4096), 16, 0, 0);
+      }
+    }
+    if (wave < 2) {  // wave 0: lse[64], wave 1: delta[64]
+      const float* src = lbase + min(qt * DKV_QT + (int)ln, a.S - 1);
+      __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)((lds_char*)smem + 0x10000 + buf * 512 + wave * 256), 4, 0, 0);
+    }
+  };
+
+  f32x16_t dk[4], dv[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { dk[i][e] = 0.f; dv[i][e] = 0.f; }
+
+  int qt = next_qt(0);
+  if (qt < nqt) stage(0, qt);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int cur = 0;
+  while (qt < nqt) {
+    const int qtn = next_qt(qt + 1);
+    if (qtn < nqt) stage(cur ^ 1, qtn);
+    // lane constants of the three LDS read patterns, recomputed per tile from a fresh lane id (kept live across the loop
+    // they are spilled; element maps as in tr_frag / row_frag)
+    uint32_t ln;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
+    const uint32_t lr_ = ln & 31, lh_ = ln >> 5;
+    const uint32_t Lr = sbase + cur * 0x8000 + lr_ * 256 + ((lh_ ^ dual_swz(lr_)) << 4);
+    const uint32_t tq = (ln & 15) >> 2, tp = ln & 3, tsub = (ln >> 4) & 1, trow = 4 * lh_ + tq;
+    const uint32_t Tl = sbase + cur * 0x8000 + trow * 256 + (((2 * tsub + (tp >> 1)) ^ dual_swz(trow)) << 4) + ((tp & 1) << 3);
+    const uint32_t Th = sbase + cur * 0x8000 + (trow + 8) * 256 + (((2 * tsub + (tp >> 1)) ^ dual_swz(trow + 8)) << 4) + ((tp & 1) << 3);
+    const uint32_t Ls = sbase + 0x10000 + cur * 512 + lh_ * 16;
+    int cls = block_class(qt, my_kt);
+    if (cls == 2 && (qt * DKV_QT + DKV_QT > a.S)) cls = 1;
+    if (cls != 0) {
+#pragma unroll
+      for (int qb32 = 0; qb32 < 2; ++qb32) {
+        f32x16_t st, dp;
+        const f32x16_t zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+          lds_char* pa = (lds_char*)(uintptr_t)xor_imm(Lr, ks << 5);
+          const bf16x8_t qa = *(lds_bf16x8*)(pa + qb32 * 8192);
+          const bf16x8_t da = *(lds_bf16x8*)(pa + qb32 * 8192 + 0x4000);
+          st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[ks], ks == 0 ? zero : st, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf[ks], ks == 0 ? zero : dp, 0, 0, 0);
+        }
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const int ql = qb32 * 32 + 8 * g4 + 4 * hh;
+          const f32x4_t l4 = *(lds_f32x4*)((lds_char*)(uintptr_t)Ls + (qb32 * 32 + 8 * g4) * 4);
+          const f32x4_t d4 = *(lds_f32x4*)((lds_char*)(uintptr_t)Ls + 256 + (qb32 * 32 + 8 * g4) * 4);
+#pragma unroll
+          for (int e2 = 0; e2 < 4; ++e2) {
+            const int e = 4 * g4 + e2;
+            const float lse = (l4[e2] == -INFINITY) ? 0.f : l4[e2];
+            float p = __builtin_amdgcn_exp2f(__builtin_fmaf(st[e], a.scale_log2, -lse));
+            if (cls != 2) {
+              const int qi = qt * DKV_QT + ql + e2;
+              bool ok = (qi < a.S) && (key < a.S) && (key <= qi || key < my_prefix);
+              if constexpr (GENERAL) {
+                const int qd = docrow ? docrow[min(qi, a.S - 1)] : key_doc;
+                ok = ok && (qd == key_doc);
+              }
+              p = ok ? p : 0.f;
+            }
+            st[e] = p;
+            dp[e] = p * (dp[e] - d4[e2]);
+          }
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          bf16x8_t pb, dsb;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { pb[j] = (__bf16)st[8 * s2 + j]; dsb[j] = (__bf16)dp[8 * s2 + j]; }
+#pragma unroll
+          for (int db = 0; db < 4; ++db) {
+            lds_char* plo = (lds_char*)(uintptr_t)xor_imm(Tl, db << 6) + (qb32 * 32 + s2 * 16) * 256;
+            lds_char* phi = (lds_char*)(uintptr_t)xor_imm(Th, db << 6) + (qb32 * 32 + s2 * 16) * 256;
+            const s16x4_t qlo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)plo);
+            const s16x4_t qhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)phi);
+            const s16x4_t dlo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(plo + 0x4000));
+            const s16x4_t dhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(phi + 0x4000));
+            const s16x8_t qv = {qlo[0], qlo[1], qlo[2], qlo[3], qhi[0], qhi[1], qhi[2], qhi[3]};
+            const s16x8_t dvv = {dlo[0], dlo[1], dlo[2], dlo[3], dhi[0], dhi[1], dhi[2], dhi[3]};
+            dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, dvv), pb, dv[db], 0, 0, 0);
+            dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, qv), dsb, dk[db], 0, 0, 0);
+          }
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    cur ^= 1;
+    qt = qtn;
+  }
+
+  const int64_t plane = (int64_t)a.B * a.S * a.KVH * HD;
+  if (key < a.S) {
+    float* pk = part + (int64_t)(g * 2 + 0) * plane + (((int64_t)b * a.S + key) * a.KVH + kvh) * HD;
+    float* pv = part + (int64_t)(g * 2 + 1) * plane + (((int64_t)b * a.S + key) * a.KVH + kvh) * HD;
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int d = 32 * db + 8 * g4 + 4 * hh;
+        *reinterpret_cast<f32x4_t*>(pk + d) = f32x4_t{dk[db][4 * g4], dk[db][4 * g4 + 1], dk[db][4 * g4 + 2], dk[db][4 * g4 + 3]};
+        *reinterpret_cast<f32x4_t*>(pv + d) = f32x4_t{dv[db][4 * g4], dv[db][4 * g4 + 1], dv[db][4 * g4 + 2], dv[db][4 * g4 + 3]};
+      }
+  }
+}
+
 // dk = bf16(scale * sum_g partK[g]) ; dv = bf16(sum_g partV[g]);  8 elements per thread.
 __global__ void attn_dkv_reduce_kernel(const AttnBwdArgs a, const float* __restrict__ part) {
   const int G = a.H / a.KVH;
@@ -464,7 +672,8 @@ extern "C" int llx_attn_bwd(const void* q, int64_t q_sb, int64_t q_ss, const voi
     hipError_t e1 = hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, DQ_LDS_BYTES);
     hipError_t e4 = hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, DQ_LDS_BYTES);
     hipError_t e5 = hipFuncSetAttribute((const void*)attn_bwd_dkv2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS_BYTES);
-    hipError_t e2 = hipSuccess;
+    hipError_t e2 = hipFuncSetAttribute((const void*)attn_bwd_dkv3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV3_LDS_BYTES);
+    if (e2 == hipSuccess) e2 = hipFuncSetAttribute((const void*)attn_bwd_dkv3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV3_LDS_BYTES);
     hipError_t e3 = hipFuncSetAttribute((const void*)attn_bwd_dkv2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS_BYTES);
     if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess || e5 != hipSuccess) { llx_set_error("llx_attn_bwd: cannot raise LDS limit"); return LLX_ERR_LAUNCH; }
     g_bwd_attr = true;
@@ -483,8 +692,14 @@ extern "C" int llx_attn_bwd(const void* q, int64_t q_sb, int64_t q_ss, const voi
   {
     float* part = delta + B * H * S;
     const int64_t nkb = cdiv64(S, DKV2_KEYS);
-    if (a.flags) hipLaunchKernelGGL(attn_bwd_dkv2_kernel<true>, dim3((unsigned)(nkb * B * H)), dim3(256), DKV_LDS_BYTES, stream, a, part);
-    else hipLaunchKernelGGL(attn_bwd_dkv2_kernel<false>, dim3((unsigned)(nkb * B * H)), dim3(256), DKV_LDS_BYTES, stream, a, part);
+    static const int dkv_variant = getenv("LLX_ATTN_DKV") ? atoi(getenv("LLX_ATTN_DKV")) : 3;
+    if (dkv_variant == 2) {
+      if (a.flags) hipLaunchKernelGGL(attn_bwd_dkv2_kernel<true>, dim3((unsigned)(nkb * B * H)), dim3(256), DKV_LDS_BYTES, stream, a, part);
+      else hipLaunchKernelGGL(attn_bwd_dkv2_kernel<false>, dim3((unsigned)(nkb * B * H)), dim3(256), DKV_LDS_BYTES, stream, a, part);
+    } else {
+      if (a.flags) hipLaunchKernelGGL(attn_bwd_dkv3_kernel<true>, dim3((unsigned)(nkb * B * H)), dim3(256), DKV3_LDS_BYTES, stream, a, part);
+      else hipLaunchKernelGGL(attn_bwd_dkv3_kernel<false>, dim3((unsigned)(nkb * B * H)), dim3(256), DKV3_LDS_BYTES, stream, a, part);
+    }
     LLX_LAUNCH_CHECK("llx_attn_bwd(dkv2)");
     const int64_t plane = B * S * KVH * HD;
     hipLaunchKernelGGL(attn_dkv_reduce_kernel, dim3((unsigned)cdiv64(plane / 8, 256)), dim3(256), 0, stream, a, (const float*)part);
