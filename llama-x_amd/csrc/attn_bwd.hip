@@ -48,7 +48,7 @@ __device__ __forceinline__ bf16x8_t row_frag(const char* img, int row, int ks, i
 
 struct AttnBwdArgs {
   const bf16_t* q; const bf16_t* k; const bf16_t* v; const bf16_t* o; const bf16_t* d_o;
-  const float* lse; float* delta;
+  const float* lse; float* delta; float* nlse;
   bf16_t* dq; bf16_t* dk; bf16_t* dv;
   int64_t q_sb, q_ss, k_sb, k_ss, v_sb, v_ss, o_sb, o_ss, do_sb, do_ss;
   int64_t dq_sb, dq_ss, dk_sb, dk_ss, dv_sb, dv_ss;
@@ -80,6 +80,8 @@ __global__ void attn_delta_kernel(const AttnBwdArgs a) {
     const int64_t bs = row / a.H;
     const int s = (int)(bs % a.S), b = (int)(bs / a.S);
     a.delta[((int64_t)b * a.H + h) * a.S + s] = acc;
+    const float l = a.lse[((int64_t)b * a.H + h) * a.S + s];
+    a.nlse[((int64_t)b * a.H + h) * a.S + s] = (l == -INFINITY) ? 0.f : -l;  // what the dK/dV kernel adds inside exp2
   }
 }
 
@@ -418,6 +420,43 @@ typedef __attribute__((address_space(3))) bf16x8_t lds_bf16x8;
 typedef __attribute__((address_space(3))) f32x4_t lds_f32x4;
 #define DKV3_LDS_BYTES (0x10000 + 1024)
 
+// ---- LDS reads hipcc does not count (guide: 'loads hipcc must not wait for').  A transposed-read intrinsic issued while the
+// next tile's LDS-DMA is in flight makes hipcc insert `s_waitcnt vmcnt(0)` (it cannot prove the two LDS regions disjoint), i.e.
+// the prefetch is drained in the middle of every tile.  As asm statements the reads are invisible to that bookkeeping; each
+// destination is named "+v" by the wait that precedes its first consumer, so no MFMA can be scheduled above the wait.
+template <int OFF>
+__device__ __forceinline__ void lds_rd128(u32x4_t& d, uint32_t addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
+}
+template <int OFF>
+__device__ __forceinline__ void lds_rdtr(u32x2_t& d, uint32_t addr) {
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
+}
+template <int N>
+__device__ __forceinline__ void lds_wait(u32x4_t& a, u32x4_t& b) {
+  asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N));
+}
+template <int N>
+__device__ __forceinline__ void lds_wait(u32x2_t& a, u32x2_t& b, u32x2_t& c, u32x2_t& d) {
+  asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N));
+}
+template <int N>
+__device__ __forceinline__ void lds_wait1(u32x4_t& a) {
+  asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a) : "n"(N));
+}
+__device__ __forceinline__ bf16x8_t frag_of(const u32x4_t& v) { return __builtin_bit_cast(bf16x8_t, v); }
+__device__ __forceinline__ bf16x8_t frag_of(const u32x2_t& lo, const u32x2_t& hi) {
+  const u32x4_t v = {lo[0], lo[1], hi[0], hi[1]};
+  return __builtin_bit_cast(bf16x8_t, v);
+}
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
 // a ^ c issued where it is written: as plain C++ hipcc computes all the XORed addresses of a tile up front and keeps them live
 __device__ __forceinline__ uint32_t xor_imm(uint32_t a, int c) {
   if (c == 0) return a;
@@ -442,23 +481,23 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv3_kernel(const AttnBwdArgs
   id -= b * (a.KVH * G);
   const int kvh = id / G, g = id % G;
   const int h = kvh * G + g;
-  const int r = lane & 31, hh = lane >> 5;
-  const int key = kblk * DKV2_KEYS + wave * 32 + r;
-  const int krow = min(key, a.S - 1);
   const int my_kt = 2 * kblk + (wave >> 1);
 
+  // (lane-derived values are not kept across the tile loop: each tile and the epilogue rebuild them from a fresh lane id)
   bf16x8_t kf[8], vf[8];
+  const int* docrow = (GENERAL && a.doc_ids) ? a.doc_ids + (int64_t)b * a.S : nullptr;
+  int key_doc = 0;
   {
-    const bf16_t* kp = a.k + (int64_t)b * a.k_sb + (int64_t)krow * a.k_ss + kvh * HD + 8 * hh;
-    const bf16_t* vp = a.v + (int64_t)b * a.v_sb + (int64_t)krow * a.v_ss + kvh * HD + 8 * hh;
+    const int krow = min(kblk * DKV2_KEYS + wave * 32 + (lane & 31), a.S - 1);
+    const bf16_t* kp = a.k + (int64_t)b * a.k_sb + (int64_t)krow * a.k_ss + kvh * HD + 8 * (lane >> 5);
+    const bf16_t* vp = a.v + (int64_t)b * a.v_sb + (int64_t)krow * a.v_ss + kvh * HD + 8 * (lane >> 5);
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
       kf[ks] = *reinterpret_cast<const bf16x8_t*>(kp + 16 * ks);
       vf[ks] = *reinterpret_cast<const bf16x8_t*>(vp + 16 * ks);
     }
+    if (docrow) key_doc = docrow[krow];
   }
-  const int* docrow = (GENERAL && a.doc_ids) ? a.doc_ids + (int64_t)b * a.S : nullptr;
-  const int key_doc = docrow ? docrow[krow] : 0;
   const int my_prefix = (GENERAL && a.prefix_len) ? a.prefix_len[b] : 0;
 
   const int qt_first = GENERAL ? 0 : (kblk * DKV2_KEYS) / DKV_QT;
@@ -480,7 +519,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv3_kernel(const AttnBwdArgs
   // Lane offsets are rebuilt from a fresh lane id per call for the same reason as the read constants.
   const char* qbase = (const char*)(a.q + (int64_t)b * a.q_sb + h * HD);
   const char* dbase = (const char*)(a.d_o + (int64_t)b * a.do_sb + h * HD);
-  const float* lbase = (wave == 0 ? a.lse : a.delta) + ((int64_t)b * a.H + h) * a.S;
+  const float* lbase = (wave == 0 ? a.nlse : a.delta) + ((int64_t)b * a.H + h) * a.S;
   auto stage = [&](int buf, int qt) {
     uint32_t ln;
     asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
@@ -534,6 +573,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv3_kernel(const AttnBwdArgs
     const uint32_t Tl = sbase + cur * 0x8000 + trow * 256 + (((2 * tsub + (tp >> 1)) ^ dual_swz(trow)) << 4) + ((tp & 1) << 3);
     const uint32_t Th = sbase + cur * 0x8000 + (trow + 8) * 256 + (((2 * tsub + (tp >> 1)) ^ dual_swz(trow + 8)) << 4) + ((tp & 1) << 3);
     const uint32_t Ls = sbase + 0x10000 + cur * 512 + lh_ * 16;
+    const int hh = (int)lh_;
+    const int key = kblk * DKV2_KEYS + wave * 32 + (int)lr_;
     int cls = block_class(qt, my_kt);
     if (cls == 2 && (qt * DKV_QT + DKV_QT > a.S)) cls = 1;
     if (cls != 0) {
@@ -541,42 +582,52 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv3_kernel(const AttnBwdArgs
       for (int qb32 = 0; qb32 < 2; ++qb32) {
         f32x16_t st, dp;
         const f32x16_t zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        // ---- S = Q.K^T, then (softmax as VALU the scheduler may place under it) dP = dO.V^T: one fragment stream at a time
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
           lds_char* pa = (lds_char*)(uintptr_t)xor_imm(Lr, ks << 5);
-          const bf16x8_t qa = *(lds_bf16x8*)(pa + qb32 * 8192);
-          const bf16x8_t da = *(lds_bf16x8*)(pa + qb32 * 8192 + 0x4000);
-          st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[ks], ks == 0 ? zero : st, 0, 0, 0);
-          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf[ks], ks == 0 ? zero : dp, 0, 0, 0);
+          st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(lds_bf16x8*)(pa + qb32 * 8192), kf[ks], ks == 0 ? zero : st, 0, 0, 0);
+        }
+        if (cls != 2) {  // ONE wave-uniform branch per 32 query rows: masked scores become -inf, exp2 turns them into 0
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int qi = qt * DKV_QT + qb32 * 32 + 8 * (e >> 2) + 4 * hh + (e & 3);
+            bool ok = (qi < a.S) && (key < a.S) && (key <= qi || key < my_prefix);
+            if constexpr (GENERAL) {
+              const int qd = docrow ? docrow[min(qi, a.S - 1)] : key_doc;
+              ok = ok && (qd == key_doc);
+            }
+            st[e] = ok ? st[e] : -INFINITY;
+          }
         }
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
-          const int ql = qb32 * 32 + 8 * g4 + 4 * hh;
+          // stats hold -lse with -inf rows sanitised to 0 (written by attn_delta_kernel)
           const f32x4_t l4 = *(lds_f32x4*)((lds_char*)(uintptr_t)Ls + (qb32 * 32 + 8 * g4) * 4);
+#pragma unroll
+          for (int e2 = 0; e2 < 4; ++e2) st[4 * g4 + e2] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[4 * g4 + e2], a.scale_log2, l4[e2]));
+        }
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+          lds_char* pa = (lds_char*)(uintptr_t)xor_imm(Lr, ks << 5);
+          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(lds_bf16x8*)(pa + qb32 * 8192 + 0x4000), vf[ks], ks == 0 ? zero : dp, 0, 0, 0);
+        }
+        // dS = P (dP - delta); P and dS are packed to bf16 for BOTH 16-row k-steps before the second phase starts, so that
+        // phase holds 16 operand registers instead of the 32 fp32 ones (the register peak of this kernel)
+        bf16x8_t pb[2], dsb[2];
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
           const f32x4_t d4 = *(lds_f32x4*)((lds_char*)(uintptr_t)Ls + 256 + (qb32 * 32 + 8 * g4) * 4);
 #pragma unroll
           for (int e2 = 0; e2 < 4; ++e2) {
             const int e = 4 * g4 + e2;
-            const float lse = (l4[e2] == -INFINITY) ? 0.f : l4[e2];
-            float p = __builtin_amdgcn_exp2f(__builtin_fmaf(st[e], a.scale_log2, -lse));
-            if (cls != 2) {
-              const int qi = qt * DKV_QT + ql + e2;
-              bool ok = (qi < a.S) && (key < a.S) && (key <= qi || key < my_prefix);
-              if constexpr (GENERAL) {
-                const int qd = docrow ? docrow[min(qi, a.S - 1)] : key_doc;
-                ok = ok && (qd == key_doc);
-              }
-              p = ok ? p : 0.f;
-            }
-            st[e] = p;
-            dp[e] = p * (dp[e] - d4[e2]);
+            pb[e >> 3][e & 7] = (__bf16)st[e];
+            dsb[e >> 3][e & 7] = (__bf16)(st[e] * (dp[e] - d4[e2]));
           }
         }
+        // ---- dV^T += dO^T.P, dK^T += Q^T.dS
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-          bf16x8_t pb, dsb;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) { pb[j] = (__bf16)st[8 * s2 + j]; dsb[j] = (__bf16)dp[8 * s2 + j]; }
+        for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
           for (int db = 0; db < 4; ++db) {
             lds_char* plo = (lds_char*)(uintptr_t)xor_imm(Tl, db << 6) + (qb32 * 32 + s2 * 16) * 256;
@@ -587,10 +638,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv3_kernel(const AttnBwdArgs
             const s16x4_t dhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(phi + 0x4000));
             const s16x8_t qv = {qlo[0], qlo[1], qlo[2], qlo[3], qhi[0], qhi[1], qhi[2], qhi[3]};
             const s16x8_t dvv = {dlo[0], dlo[1], dlo[2], dlo[3], dhi[0], dhi[1], dhi[2], dhi[3]};
-            dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, dvv), pb, dv[db], 0, 0, 0);
-            dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, qv), dsb, dk[db], 0, 0, 0);
+            dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, dvv), pb[s2], dv[db], 0, 0, 0);
+            dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, qv), dsb[s2], dk[db], 0, 0, 0);
           }
-        }
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -600,6 +650,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv3_kernel(const AttnBwdArgs
   }
 
   const int64_t plane = (int64_t)a.B * a.S * a.KVH * HD;
+  uint32_t le;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(le));
+  const int hh = (int)(le >> 5);
+  const int key = kblk * DKV2_KEYS + wave * 32 + (int)(le & 31);
   if (key < a.S) {
     float* pk = part + (int64_t)(g * 2 + 0) * plane + (((int64_t)b * a.S + key) * a.KVH + kvh) * HD;
     float* pv = part + (int64_t)(g * 2 + 1) * plane + (((int64_t)b * a.S + key) * a.KVH + kvh) * HD;
@@ -647,9 +701,9 @@ __global__ void attn_dkv_reduce_kernel(const AttnBwdArgs a, const float* __restr
 
 static bool g_bwd_attr = false;
 
-// fp32 workspace of llx_attn_bwd: delta [B,H,S] followed by the dK/dV partials [G][2][B,S,KVH,128].
+// fp32 workspace of llx_attn_bwd: delta [B,H,S], sanitised -lse [B,H,S], then the dK/dV partials [G][2][B,S,KVH,128].
 extern "C" int64_t llx_attn_bwd_workspace_bytes(int64_t B, int64_t S, int64_t H, int64_t KVH) {
-  return (B * H * S + (H / KVH) * 2 * B * S * KVH * HD) * 4;
+  return (2 * B * H * S + (H / KVH) * 2 * B * S * KVH * HD) * 4;
 }
 
 // delta: fp32 workspace of llx_attn_bwd_workspace_bytes() bytes.  All strides in elements.  flags as in llx_attn_fwd.
@@ -680,7 +734,7 @@ extern "C" int llx_attn_bwd(const void* q, int64_t q_sb, int64_t q_ss, const voi
   }
   AttnBwdArgs a;
   a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.o = (const bf16_t*)o; a.d_o = (const bf16_t*)d_o;
-  a.lse = lse; a.delta = delta; a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk; a.dv = (bf16_t*)dv;
+  a.lse = lse; a.delta = delta; a.nlse = delta + B * H * S; a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk; a.dv = (bf16_t*)dv;
   a.q_sb = q_sb; a.q_ss = q_ss; a.k_sb = k_sb; a.k_ss = k_ss; a.v_sb = v_sb; a.v_ss = v_ss; a.o_sb = o_sb; a.o_ss = o_ss;
   a.do_sb = do_sb; a.do_ss = do_ss; a.dq_sb = dq_sb; a.dq_ss = dq_ss; a.dk_sb = dk_sb; a.dk_ss = dk_ss; a.dv_sb = dv_sb; a.dv_ss = dv_ss;
   a.doc_ids = doc_ids; a.prefix_len = prefix_len; a.flags = (doc_ids || prefix_len) ? (const uint8_t*)flags : nullptr;
@@ -690,7 +744,7 @@ extern "C" int llx_attn_bwd(const void* q, int64_t q_sb, int64_t q_ss, const voi
   hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)cdiv64(rows, 16)), dim3(256), 0, stream, a);
   LLX_LAUNCH_CHECK("llx_attn_bwd(delta)");
   {
-    float* part = delta + B * H * S;
+    float* part = delta + 2 * B * H * S;
     const int64_t nkb = cdiv64(S, DKV2_KEYS);
     static const int dkv_variant = getenv("LLX_ATTN_DKV") ? atoi(getenv("LLX_ATTN_DKV")) : 3;
     if (dkv_variant == 2) {
