@@ -64,6 +64,7 @@ int llx_quantize_int8_rowwise(const void* x, int64_t ldx, void* q, int64_t ldq, 
  *      flags: tile classes built by llx_attn_tile_flags (needed only with doc_ids / prefix_len). ----------------- */
 int llx_debug_attn_fwd_stamps(const void* q, const void* k, const void* v, void* o, int64_t S, int64_t H, int64_t KVH,
                               unsigned long long* stamps, llx_stream_t s); /* diagnostic: in-kernel s_memtime stamps, timing only */
+int llx_debug_attn_bwd_set_stamps(unsigned long long* stamps); /* diagnostic: stamp build of the dK/dV kernel for the next llx_attn_bwd calls */
 int llx_debug_attn_fwd_occupancy(void); /* diagnostic: workgroups per CU granted to the forward kernel */
 int64_t llx_attn_flags_bytes(int64_t B, int64_t S);
 int llx_attn_tile_flags(const int* doc_ids, const int* prefix_len, void* flags, int64_t B, int64_t S, llx_stream_t s);

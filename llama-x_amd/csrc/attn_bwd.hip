@@ -49,6 +49,7 @@ __device__ __forceinline__ bf16x8_t row_frag(const char* img, int row, int ks, i
 struct AttnBwdArgs {
   const bf16_t* q; const bf16_t* k; const bf16_t* v; const bf16_t* o; const bf16_t* d_o;
   const float* lse; float* delta; float* nlse;
+  unsigned long long* stamps;  // diagnostic (normally null): s_memtime stamps of workgroup 0, wave 0 of the dK/dV kernel
   bf16_t* dq; bf16_t* dk; bf16_t* dv;
   int64_t q_sb, q_ss, k_sb, k_ss, v_sb, v_ss, o_sb, o_ss, do_sb, do_ss;
   int64_t dq_sb, dq_ss, dk_sb, dk_ss, dv_sb, dv_ss;
@@ -465,7 +466,7 @@ __device__ __forceinline__ uint32_t xor_imm(uint32_t a, int c) {
   return r;
 }
 
-template <bool GENERAL>
+template <bool GENERAL, bool STAMP = false>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv3_kernel(const AttnBwdArgs a, float* __restrict__ part) {
   extern __shared__ __attribute__((aligned(256))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -520,33 +521,36 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv3_kernel(const AttnBwdArgs
   const char* qbase = (const char*)(a.q + (int64_t)b * a.q_sb + h * HD);
   const char* dbase = (const char*)(a.d_o + (int64_t)b * a.do_sb + h * HD);
   const float* lbase = (wave == 0 ? a.nlse : a.delta) + ((int64_t)b * a.H + h) * a.S;
-  auto stage = [&](int buf, int qt) {
+  // One LDS-DMA piece = 1 KiB = 4 rows of one image per wave-instruction; piece p < 8: image p&1 (Q / dO), row group p>>1;
+  // piece 8: the row statistics (waves 0 and 1).  (Spreading the pieces between the MFMAs of the first S chain instead of
+  // bursting them at the top of the tile was tried: hipcc then spills ~120 registers; the burst costs ~1.4k cycles per tile.)
+  auto stage_piece = [&](int buf, int qt, int p) {
     uint32_t ln;
     asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
+    if (p == 8) {
+      if (wave < 2) {  // wave 0: -lse[64] (sanitised), wave 1: delta[64]
+        const float* src = lbase + min(qt * DKV_QT + (int)ln, a.S - 1);
+        __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)((lds_char*)smem + 0x10000 + buf * 512 + wave * 256), 4, 0, 0);
+      }
+      return;
+    }
+    const int img = p & 1, i = p >> 1;
     const uint32_t srow = wave * 4 + (ln >> 4);
     const uint32_t sc = (ln & 15) ^ dual_swz(srow);
-    lds_char* sQ = (lds_char*)smem + buf * 0x8000 + wave * 1024;
+    lds_char* dst = (lds_char*)smem + buf * 0x8000 + img * 0x4000 + i * 4096 + wave * 1024;
+    const char* base = img ? dbase : qbase;
+    const int64_t ss = img ? a.do_ss : a.q_ss;
     if (qt * DKV_QT + DKV_QT <= a.S) {
-      const uint32_t q_lane = (srow * (uint32_t)a.q_ss + sc * 8) * 2, d_lane = (srow * (uint32_t)a.do_ss + sc * 8) * 2;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const char* qu = qbase + (int64_t)(qt * DKV_QT + i * 16) * a.q_ss * 2;   // wave-uniform
-        const char* du = dbase + (int64_t)(qt * DKV_QT + i * 16) * a.do_ss * 2;
-        __builtin_amdgcn_global_load_lds((gbl_void*)(qu + q_lane), (lds_void*)(sQ + i * 4096), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gbl_void*)(du + d_lane), (lds_void*)(sQ + 0x4000 + i * 4096), 16, 0, 0);
-      }
+      const char* u = base + (int64_t)(qt * DKV_QT + i * 16) * ss * 2;  // wave-uniform
+      __builtin_amdgcn_global_load_lds((gbl_void*)(u + (srow * (uint32_t)ss + sc * 8) * 2), (lds_void*)dst, 16, 0, 0);
     } else {  // ragged last tile: clamp the row per lane
+      const int qr = min(qt * DKV_QT + i * 16 + (int)srow, a.S - 1);
+      __builtin_amdgcn_global_load_lds((gbl_void*)(base + ((int64_t)qr * ss + sc * 8) * 2), (lds_void*)dst, 16, 0, 0);
+    }
+  };
+  auto stage = [&](int buf, int qt) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int qr = min(qt * DKV_QT + i * 16 + (int)srow, a.S - 1);
-        __builtin_amdgcn_global_load_lds((gbl_void*)(qbase + ((int64_t)qr * a.q_ss + sc * 8) * 2), (lds_void*)(sQ + i * 4096), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gbl_void*)(dbase + ((int64_t)qr * a.do_ss + sc * 8) * 2), (lds_void*)(sQ + 0x4000 + i * 4096), 16, 0, 0);
-      }
-    }
-    if (wave < 2) {  // wave 0: lse[64], wave 1: delta[64]
-      const float* src = lbase + min(qt * DKV_QT + (int)ln, a.S - 1);
-      __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)((lds_char*)smem + 0x10000 + buf * 512 + wave * 256), 4, 0, 0);
-    }
+    for (int p = 0; p < 9; ++p) stage_piece(buf, qt, p);
   };
 
   f32x16_t dk[4], dv[4];
@@ -560,9 +564,21 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv3_kernel(const AttnBwdArgs
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   int cur = 0;
+  int nst = 0;
+  auto stamp = [&]() {
+    if constexpr (STAMP) {
+      if (blockIdx.x == 0 && wave == 0 && nst < 1024) {
+        unsigned long long tt;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tt) :: "memory");
+        if (threadIdx.x == 0) a.stamps[nst] = tt;
+        ++nst;
+      }
+    }
+  };
   while (qt < nqt) {
+    stamp();  // 0: tile start
     const int qtn = next_qt(qt + 1);
-    if (qtn < nqt) stage(cur ^ 1, qtn);
+    const bool have_next = qtn < nqt;
     // lane constants of the three LDS read patterns, recomputed per tile from a fresh lane id (kept live across the loop
     // they are spilled; element maps as in tr_frag / row_frag)
     uint32_t ln;
@@ -577,17 +593,40 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv3_kernel(const AttnBwdArgs
     const int key = kblk * DKV2_KEYS + wave * 32 + (int)lr_;
     int cls = block_class(qt, my_kt);
     if (cls == 2 && (qt * DKV_QT + DKV_QT > a.S)) cls = 1;
+    if (have_next) stage(cur ^ 1, qtn);
+    stamp();  // 1: next tile's DMA issued
     if (cls != 0) {
+      auto rowf = [&](int qb32, int img, int ks) -> bf16x8_t {
+        return *(lds_bf16x8*)((lds_char*)(uintptr_t)xor_imm(Lr, ks << 5) + qb32 * 8192 + img * 0x4000);
+      };
+      auto trf = [&](int qb32, int img, int step) -> bf16x8_t {  // step = (s2, db)
+        const int s2 = step >> 2, db = step & 3;
+        lds_char* plo = (lds_char*)(uintptr_t)xor_imm(Tl, db << 6) + (qb32 * 32 + s2 * 16) * 256 + img * 0x4000;
+        lds_char* phi = (lds_char*)(uintptr_t)xor_imm(Th, db << 6) + (qb32 * 32 + s2 * 16) * 256 + img * 0x4000;
+        const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)plo);
+        const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)phi);
+        const s16x8_t v8 = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(bf16x8_t, v8);
+      };
 #pragma unroll
       for (int qb32 = 0; qb32 < 2; ++qb32) {
         f32x16_t st, dp;
         const f32x16_t zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        // ---- S = Q.K^T, then (softmax as VALU the scheduler may place under it) dP = dO.V^T: one fragment stream at a time
+        // ---- S = Q.K^T: fragments two k-steps ahead (sched_barrier pins the order; hipcc counts the lgkmcnt ladder)
+        bf16x8_t f3[3];
+        f3[0] = rowf(qb32, 0, 0);
+        f3[1] = rowf(qb32, 0, 1);
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
-          lds_char* pa = (lds_char*)(uintptr_t)xor_imm(Lr, ks << 5);
-          st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(lds_bf16x8*)(pa + qb32 * 8192), kf[ks], ks == 0 ? zero : st, 0, 0, 0);
+          if (ks + 2 < 8) f3[(ks + 2) % 3] = rowf(qb32, 0, ks + 2);
+          st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f3[ks % 3], kf[ks], ks == 0 ? zero : st, 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
         }
+        if (qb32 == 0) stamp();  // 2: S chain
+        // first dO fragments fly under the softmax
+        bf16x8_t g3[3];
+        g3[0] = rowf(qb32, 1, 0);
+        g3[1] = rowf(qb32, 1, 1);
         if (cls != 2) {  // ONE wave-uniform branch per 32 query rows: masked scores become -inf, exp2 turns them into 0
 #pragma unroll
           for (int e = 0; e < 16; ++e) {
@@ -607,11 +646,19 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv3_kernel(const AttnBwdArgs
 #pragma unroll
           for (int e2 = 0; e2 < 4; ++e2) st[4 * g4 + e2] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[4 * g4 + e2], a.scale_log2, l4[e2]));
         }
+        __builtin_amdgcn_sched_barrier(0);
+        if (qb32 == 0) stamp();  // 3: softmax
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
-          lds_char* pa = (lds_char*)(uintptr_t)xor_imm(Lr, ks << 5);
-          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(lds_bf16x8*)(pa + qb32 * 8192 + 0x4000), vf[ks], ks == 0 ? zero : dp, 0, 0, 0);
+          if (ks + 2 < 8) g3[(ks + 2) % 3] = rowf(qb32, 1, ks + 2);
+          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g3[ks % 3], vf[ks], ks == 0 ? zero : dp, 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
         }
+        if (qb32 == 0) stamp();  // 4: dP chain
+        // first transposed fragments of the second phase fly under the dS arithmetic
+        bf16x8_t td[2], tqf[2];
+        td[0] = trf(qb32, 1, 0);
+        tqf[0] = trf(qb32, 0, 0);
         // dS = P (dP - delta); P and dS are packed to bf16 for BOTH 16-row k-steps before the second phase starts, so that
         // phase holds 16 operand registers instead of the 32 fp32 ones (the register peak of this kernel)
         bf16x8_t pb[2], dsb[2];
@@ -625,26 +672,27 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv3_kernel(const AttnBwdArgs
             dsb[e >> 3][e & 7] = (__bf16)(st[e] * (dp[e] - d4[e2]));
           }
         }
-        // ---- dV^T += dO^T.P, dK^T += Q^T.dS
+        __builtin_amdgcn_sched_barrier(0);
+        if (qb32 == 0) stamp();  // 5: dS + pack
+        // ---- dV^T += dO^T.P, dK^T += Q^T.dS: step = (s2, db), the transposed fragments of the next step are in flight
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-          for (int db = 0; db < 4; ++db) {
-            lds_char* plo = (lds_char*)(uintptr_t)xor_imm(Tl, db << 6) + (qb32 * 32 + s2 * 16) * 256;
-            lds_char* phi = (lds_char*)(uintptr_t)xor_imm(Th, db << 6) + (qb32 * 32 + s2 * 16) * 256;
-            const s16x4_t qlo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)plo);
-            const s16x4_t qhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)phi);
-            const s16x4_t dlo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(plo + 0x4000));
-            const s16x4_t dhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(phi + 0x4000));
-            const s16x8_t qv = {qlo[0], qlo[1], qlo[2], qlo[3], qhi[0], qhi[1], qhi[2], qhi[3]};
-            const s16x8_t dvv = {dlo[0], dlo[1], dlo[2], dlo[3], dhi[0], dhi[1], dhi[2], dhi[3]};
-            dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, dvv), pb[s2], dv[db], 0, 0, 0);
-            dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, qv), dsb[s2], dk[db], 0, 0, 0);
+        for (int step = 0; step < 8; ++step) {
+          if (step + 1 < 8) {
+            td[(step + 1) & 1] = trf(qb32, 1, step + 1);
+            tqf[(step + 1) & 1] = trf(qb32, 0, step + 1);
           }
+          dv[step & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(td[step & 1], pb[step >> 2], dv[step & 3], 0, 0, 0);
+          dk[step & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tqf[step & 1], dsb[step >> 2], dk[step & 3], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (qb32 == 0) stamp();  // 6: 16 + 16 MFMAs of the second phase (first 32 rows)
       }
     }
+    stamp();  // 7: second 32 rows
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    stamp();  // 8: DMA wait
     __syncthreads();
+    stamp();  // 9: barrier
     cur ^= 1;
     qt = qtn;
   }
@@ -700,6 +748,11 @@ __global__ void attn_dkv_reduce_kernel(const AttnBwdArgs a, const float* __restr
 }
 
 static bool g_bwd_attr = false;
+static unsigned long long* g_bwd_stamps = nullptr;
+
+// Diagnostic: the next llx_attn_bwd calls run the dK/dV kernel build that writes s_memtime stamps (10 per query tile of
+// workgroup 0, wave 0; needs cls != 0 on every tile, i.e. the plain causal mask) into `stamps` (>= 1024 entries); null turns it off.
+extern "C" int llx_debug_attn_bwd_set_stamps(unsigned long long* stamps) { g_bwd_stamps = stamps; return LLX_OK; }
 
 // fp32 workspace of llx_attn_bwd: delta [B,H,S], sanitised -lse [B,H,S], then the dK/dV partials [G][2][B,S,KVH,128].
 extern "C" int64_t llx_attn_bwd_workspace_bytes(int64_t B, int64_t S, int64_t H, int64_t KVH) {
@@ -734,7 +787,7 @@ extern "C" int llx_attn_bwd(const void* q, int64_t q_sb, int64_t q_ss, const voi
   }
   AttnBwdArgs a;
   a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.o = (const bf16_t*)o; a.d_o = (const bf16_t*)d_o;
-  a.lse = lse; a.delta = delta; a.nlse = delta + B * H * S; a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk; a.dv = (bf16_t*)dv;
+  a.lse = lse; a.delta = delta; a.nlse = delta + B * H * S; a.stamps = nullptr; a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk; a.dv = (bf16_t*)dv;
   a.q_sb = q_sb; a.q_ss = q_ss; a.k_sb = k_sb; a.k_ss = k_ss; a.v_sb = v_sb; a.v_ss = v_ss; a.o_sb = o_sb; a.o_ss = o_ss;
   a.do_sb = do_sb; a.do_ss = do_ss; a.dq_sb = dq_sb; a.dq_ss = dq_ss; a.dk_sb = dk_sb; a.dk_ss = dk_ss; a.dv_sb = dv_sb; a.dv_ss = dv_ss;
   a.doc_ids = doc_ids; a.prefix_len = prefix_len; a.flags = (doc_ids || prefix_len) ? (const uint8_t*)flags : nullptr;
@@ -751,7 +804,11 @@ extern "C" int llx_attn_bwd(const void* q, int64_t q_sb, int64_t q_ss, const voi
       if (a.flags) hipLaunchKernelGGL(attn_bwd_dkv2_kernel<true>, dim3((unsigned)(nkb * B * H)), dim3(256), DKV_LDS_BYTES, stream, a, part);
       else hipLaunchKernelGGL(attn_bwd_dkv2_kernel<false>, dim3((unsigned)(nkb * B * H)), dim3(256), DKV_LDS_BYTES, stream, a, part);
     } else {
-      if (a.flags) hipLaunchKernelGGL(attn_bwd_dkv3_kernel<true>, dim3((unsigned)(nkb * B * H)), dim3(256), DKV3_LDS_BYTES, stream, a, part);
+      if (g_bwd_stamps && !a.flags) {
+        a.stamps = g_bwd_stamps;
+        (void)hipFuncSetAttribute((const void*)attn_bwd_dkv3_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV3_LDS_BYTES);
+        hipLaunchKernelGGL((attn_bwd_dkv3_kernel<false, true>), dim3((unsigned)(nkb * B * H)), dim3(256), DKV3_LDS_BYTES, stream, a, part);
+      } else if (a.flags) hipLaunchKernelGGL(attn_bwd_dkv3_kernel<true>, dim3((unsigned)(nkb * B * H)), dim3(256), DKV3_LDS_BYTES, stream, a, part);
       else hipLaunchKernelGGL(attn_bwd_dkv3_kernel<false>, dim3((unsigned)(nkb * B * H)), dim3(256), DKV3_LDS_BYTES, stream, a, part);
     }
     LLX_LAUNCH_CHECK("llx_attn_bwd(dkv2)");

@@ -26,6 +26,7 @@ SIGNATURES: dict[str, tuple] = {
     "llx_rmsnorm_bwd_workspace_bytes": (c_int64, [_L, _L]),
     "llx_rmsnorm_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _I, _P, _P, _L, _L, _P]),
     "llx_debug_attn_fwd_occupancy": (c_int, []),
+    "llx_debug_attn_bwd_set_stamps": (c_int, [_P]),
     "llx_debug_attn_fwd_stamps": (c_int, [_P, _P, _P, _P, _L, _L, _L, _P, _P]),
     "llx_attn_flags_bytes": (c_int64, [_L, _L]),
     "llx_attn_tile_flags": (c_int, [_P, _P, _P, _L, _L, _P]),
