@@ -195,18 +195,21 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnBwdArgs a
         dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[ks], ks == 0 ? zero : dp, 0, 0, 0);
       }
       // dS^T = P^T * (dP^T - delta)
+      if (cls != 2) {  // ONE wave-uniform branch per 32 keys: masked scores become -inf, exp2 turns them into 0
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        float p = __builtin_amdgcn_exp2f(__builtin_fmaf(st[e], a.scale_log2, -lse_safe));
-        if (cls != 2) {
+        for (int e = 0; e < 16; ++e) {
           const int kk = t * BKV + kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
           bool ok = (kk < a.S) && (kk <= qi || kk < my_prefix);
           if constexpr (GENERAL) {
             const int kd = docrow ? docrow[min(kk, a.S - 1)] : my_doc;
             ok = ok && (kd == my_doc);
           }
-          p = ok ? p : 0.f;
+          st[e] = ok ? st[e] : -INFINITY;
         }
+      }
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(st[e], a.scale_log2, -lse_safe));
         st[e] = p * (dp[e] - my_delta);
       }
 #pragma unroll
