@@ -61,36 +61,47 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restri
                                                           const bf16_t* __restrict__ dres, int64_t rows, int dim, int rows_per_block) {
   extern __shared__ __attribute__((aligned(16))) float dwsh[];  // [dim] when dw is requested
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float wv[NCH][8];
+  u32x4_t wp[NCH];  // norm weight, kept packed (unpacked where it is used)
   float dwacc[NCH][8];
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
     const int col = c * 512 + lane * 8;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { dwacc[c][e] = 0.f; wv[c][e] = 0.f; }
-    if (col < dim) {
-      const u32x4_t u = *reinterpret_cast<const u32x4_t*>(w + col);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { wv[c][2 * e] = bflo(u[e]); wv[c][2 * e + 1] = bfhi(u[e]); }
-    }
+    for (int e = 0; e < 8; ++e) dwacc[c][e] = 0.f;
+    wp[c] = u32x4_t{0u, 0u, 0u, 0u};
+    if (col < dim) wp[c] = *reinterpret_cast<const u32x4_t*>(w + col);
   }
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
-  for (int64_t row = r0 + wave; row < r0 + rows_per_block && row < rows; row += 4) {
-    const float rs = rstd[row];
-    u32x4_t xv[NCH], dv[NCH];
+  const int64_t r_end = (r0 + rows_per_block < rows) ? r0 + rows_per_block : rows;
+  // Two register sets: the loads of the wave's NEXT row are in flight while the current row is reduced and written (a
+  // block is resident once per CU at this size, so the wave has to hide its own HBM latency).  dim 8192 keeps one set.
+  constexpr bool PIPE = NCH <= 8;
+  struct RowRegs { u32x4_t x[NCH], d[NCH], r[NCH]; float rs; };
+  auto load_row = [&](RowRegs& R, int64_t row) {
+    R.rs = rstd[row];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int col = c * 512 + lane * 8;
+      if (col < dim) {
+        R.x[c] = *reinterpret_cast<const u32x4_t*>(x + row * dim + col);
+        R.d[c] = *reinterpret_cast<const u32x4_t*>(dy + row * dim + col);
+        if (dres) R.r[c] = *reinterpret_cast<const u32x4_t*>(dres + row * dim + col);
+      }
+    }
+  };
+  auto process_row = [&](RowRegs& R, int64_t row) {
+    const float rs = R.rs;
     float dot = 0.f;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       const int col = c * 512 + lane * 8;
       if (col < dim) {
-        xv[c] = *reinterpret_cast<const u32x4_t*>(x + row * dim + col);
-        dv[c] = *reinterpret_cast<const u32x4_t*>(dy + row * dim + col);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float x0 = bflo(xv[c][e]) * rs, x1 = bfhi(xv[c][e]) * rs;
-          const float d0 = bflo(dv[c][e]), d1 = bfhi(dv[c][e]);
+          const float x0 = bflo(R.x[c][e]) * rs, x1 = bfhi(R.x[c][e]) * rs;
+          const float d0 = bflo(R.d[c][e]), d1 = bfhi(R.d[c][e]);
           dwacc[c][2 * e] += d0 * x0; dwacc[c][2 * e + 1] += d1 * x1;
-          dot += d0 * wv[c][2 * e] * x0 + d1 * wv[c][2 * e + 1] * x1;
+          dot += d0 * bflo(wp[c][e]) * x0 + d1 * bfhi(wp[c][e]) * x1;
         }
       }
     }
@@ -100,22 +111,45 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restri
     for (int c = 0; c < NCH; ++c) {
       const int col = c * 512 + lane * 8;
       if (col < dim) {
-        u32x4_t rv = {0u, 0u, 0u, 0u};
-        if (dres) rv = *reinterpret_cast<const u32x4_t*>(dres + row * dim + col);
         u32x4_t o;
+        // opaque copy: without it hipcc keeps the 64 unpacked, scaled floats of the first pass alive instead of the 16 packed
+        // registers (512 VGPRs + scratch with two row sets in flight)
+        asm volatile("" : "+v"(R.x[c]), "+v"(R.d[c]));
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float x0 = bflo(xv[c][e]) * rs, x1 = bfhi(xv[c][e]) * rs;
-          float a = rs * (bflo(dv[c][e]) * wv[c][2 * e] - x0 * m);
-          float b = rs * (bfhi(dv[c][e]) * wv[c][2 * e + 1] - x1 * m);
+          const float x0 = bflo(R.x[c][e]) * rs, x1 = bfhi(R.x[c][e]) * rs;
+          float a = rs * (bflo(R.d[c][e]) * bflo(wp[c][e]) - x0 * m);
+          float b = rs * (bfhi(R.d[c][e]) * bfhi(wp[c][e]) - x1 * m);
           if (dres) {  // gradient of the residual branch joins here: bf16(dx) + dres, rounded as the eager add would
-            a = bf2f(f2bf(a)) + bflo(rv[e]);
-            b = bf2f(f2bf(b)) + bfhi(rv[e]);
+            a = bf2f(f2bf(a)) + bflo(R.r[c][e]);
+            b = bf2f(f2bf(b)) + bfhi(R.r[c][e]);
           }
           o[e] = pack_bf2(a, b);
         }
         *reinterpret_cast<u32x4_t*>(dx + row * dim + col) = o;
       }
+    }
+  };
+  {
+    RowRegs A;
+    int64_t row = r0 + wave;
+    if constexpr (PIPE) {
+      RowRegs B;
+      if (row < r_end) load_row(A, row);
+      while (row < r_end) {
+        const bool n1 = row + 4 < r_end;
+        if (n1) load_row(B, row + 4);
+        process_row(A, row);
+        if (!n1) break;
+        row += 4;
+        const bool n2 = row + 4 < r_end;
+        if (n2) load_row(A, row + 4);
+        process_row(B, row);
+        if (!n2) break;
+        row += 4;
+      }
+    } else {
+      for (; row < r_end; row += 4) { load_row(A, row); process_row(A, row); }
     }
   }
   if (dw_partial) {
@@ -138,19 +172,22 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restri
 }
 
 // dw[col] = bf16( sum_p partial[p][col] ), optionally accumulating into an existing bf16 grad.
-// Block = 64 columns x 4 row groups (256 threads): row groups split the partial rows, LDS combines them.
+// Block = 16 columns x 16 row groups (256 threads) so that a [256, 4096] partial array is summed by 256 blocks with 16
+// dependent loads per thread (64 columns x 4 groups left 64 blocks with 64 loads each: latency-bound at 17 us).
 __global__ __launch_bounds__(256) void colsum_partials_kernel(const float* __restrict__ partial, bf16_t* __restrict__ out, int nparts, int dim,
                                                               int accumulate) {
-  __shared__ float red[4][64];
-  const int c = threadIdx.x & 63, grp = threadIdx.x >> 6;
-  const int col = blockIdx.x * 64 + c;
+  __shared__ float red[16][17];
+  const int c = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  const int col = blockIdx.x * 16 + c;
   float s = 0.f;
   if (col < dim)
-    for (int p = grp; p < nparts; p += 4) s += partial[(int64_t)p * dim + col];
+    for (int p = grp; p < nparts; p += 16) s += partial[(int64_t)p * dim + col];
   red[grp][c] = s;
   __syncthreads();
   if (grp == 0 && col < dim) {
-    s = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+    s = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) s += red[g][c];
     if (accumulate) s += bf2f(out[col]);
     out[col] = f2bf(s);
   }
@@ -171,8 +208,11 @@ extern "C" int llx_rmsnorm_fwd(const void* x, const void* w, void* y, float* rst
   return LLX_OK;
 }
 
+#ifndef RMS_BWD_RPB
+#define RMS_BWD_RPB 16  // rows per 4-wave block (4 per wave): one block per CU at [4096, 4096], one dw partial row per block
+#endif
 extern "C" int64_t llx_rmsnorm_bwd_workspace_bytes(int64_t rows, int64_t dim) {
-  const int64_t rpb = 16;
+  const int64_t rpb = RMS_BWD_RPB;
   return cdiv64(rows, rpb) * dim * 4;
 }
 
@@ -184,7 +224,7 @@ extern "C" int llx_rmsnorm_bwd(const void* dy, const void* x, const void* w, con
   LLX_REQUIRE(dim > 0 && dim % 8 == 0 && dim <= 8192, "llx_rmsnorm_bwd: dim=%lld must be a multiple of 8 and <= 8192", (long long)dim);
   LLX_REQUIRE(!dw || workspace, "llx_rmsnorm_bwd: workspace required when dw is requested");
   if (rows == 0) return LLX_OK;
-  const int rpb = 16;
+  const int rpb = RMS_BWD_RPB;
   const int nblk = (int)cdiv64(rows, rpb);
   const int nch = (int)cdiv64(dim, 512);
   float* part = dw ? (float*)workspace : nullptr;
@@ -194,7 +234,7 @@ extern "C" int llx_rmsnorm_bwd(const void* dy, const void* x, const void* w, con
 #undef L
   LLX_LAUNCH_CHECK("llx_rmsnorm_bwd");
   if (dw) {
-    hipLaunchKernelGGL(colsum_partials_kernel, dim3((unsigned)cdiv64(dim, 64)), dim3(256), 0, stream, part, (bf16_t*)dw, nblk,
+    hipLaunchKernelGGL(colsum_partials_kernel, dim3((unsigned)cdiv64(dim, 16)), dim3(256), 0, stream, part, (bf16_t*)dw, nblk,
                        (int)dim, dw_accumulate);
     LLX_LAUNCH_CHECK("llx_rmsnorm_bwd(colsum)");
   }
