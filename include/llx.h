@@ -111,7 +111,8 @@ int llx_ce_fwd_bwd(const void* logits, int64_t ld, void* dlogits, int64_t dld, c
 
 /* ---- LoRA skinny contractions (modelling/lora.py:43 and its autograd): T = X.W^T -> [M,64] zero padded;
  *      G = s * U^T.Y with fp32 split partials (deterministic). --------------------------------------------------- */
-int llx_skinny_nt(const void* X, int64_t ldx, const void* W, int64_t ldw, void* out, int64_t M, int64_t K, int64_t R, llx_stream_t s);
+int llx_skinny_nt(const void* X, int64_t ldx, const void* W, int64_t ldw, void* out, int64_t M, int64_t K, int64_t R,
+                  const int32_t* kranges /* host, nullable: {lo,hi} x 4 per 16 rows of a block-diagonal W */, llx_stream_t s);
 int64_t llx_skinny_tn_workspace_bytes(int64_t M, int64_t N, int64_t R);
 int llx_skinny_tn(const void* U, const void* Y, int64_t ldy, void* out, int64_t out_ld, int64_t M, int64_t N, int64_t R, float scale,
                   int transpose_out, int accumulate, void* workspace, llx_stream_t s);

@@ -15,40 +15,66 @@ typedef __attribute__((ext_vector_type(8))) short s16x8_t;
 #define SNT_WAVES 8
 #define SNT_UNROLL 8
 
-template <int NB>
+// Block-diagonal W (the batched LoRA B^T of a fused linear group: rows 16*nb.. only meet k in [lo[nb], hi[nb])): the k-steps
+// outside a row block's range are skipped - no W fragment load, no MFMA.  Dense W: lo = 0, hi = K.
+struct SkinnyRanges { int lo[4], hi[4]; };
+
+template <int NB, bool RANGED>
 __global__ __launch_bounds__(SNT_WAVES * 64) void skinny_nt_kernel(const bf16_t* __restrict__ X, int64_t ldx, const bf16_t* __restrict__ W,
-                                                                   int64_t ldw, bf16_t* __restrict__ out, int M, int K, int R) {
+                                                                   int64_t ldw, bf16_t* __restrict__ out, int M, int K, int R, SkinnyRanges kr) {
   __shared__ float part[SNT_WAVES][16][SK_PAD];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int m0 = blockIdx.x * 16;
   const int fr = lane & 15, fq = lane >> 4;
-  const bf16_t* xp = X + (int64_t)min(m0 + fr, M - 1) * ldx + 8 * fq;
-  const bf16_t* wp[NB];
+  const bf16_t* xrow = X + (int64_t)min(m0 + fr, M - 1) * ldx;
+  const bf16_t* wrow[NB];
 #pragma unroll
-  for (int nb = 0; nb < NB; ++nb) wp[nb] = W + (int64_t)min(nb * 16 + fr, R - 1) * ldw + 8 * fq;
+  for (int nb = 0; nb < NB; ++nb) wrow[nb] = W + (int64_t)min(nb * 16 + fr, R - 1) * ldw;
   f32x4_t acc[NB];
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) acc[nb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  // The sum over k does not care which 32 k-values form one MFMA step as long as X and W use the same map.  Main loop: a
+  // PAIR of steps covers 64 consecutive k; lane (fr, fq) takes k = 64*pair + 16*fq + 8*h + 0..7 for step h, i.e. 32
+  // contiguous bytes per lane and whole 128-byte lines per row and wave (with the natural map, k = 32*step + 8*fq, a wave
+  // touches half of every line it reads and the L2 -> L1 traffic of the W fragments doubles).
+  const int npairs = K >> 6;
+  const int rounds = npairs / ((SNT_UNROLL / 2) * SNT_WAVES);  // the same trip count for every wave
+  // every block walks the same W; starting each block at its own round spreads the simultaneous W reads of an XCD's 32
+  // blocks over the L2 channels instead of queueing them on the same lines (that queue was 55 % of the K = 28672 call)
+  const int rot = rounds > 0 ? (int)((blockIdx.x * 7u + (blockIdx.x >> 3)) % (unsigned)rounds) : 0;
+  for (int it0 = 0; it0 < rounds; ++it0) {
+    const int it = (it0 + rot < rounds) ? it0 + rot : it0 + rot - rounds;
+    const int pr = it * (SNT_UNROLL / 2) * SNT_WAVES + wave;
+    bf16x8_t a[SNT_UNROLL], b[SNT_UNROLL][NB];
+#pragma unroll
+    for (int u = 0; u < SNT_UNROLL; ++u) a[u] = *reinterpret_cast<const bf16x8_t*>(xrow + (pr + (u >> 1) * SNT_WAVES) * 64 + 16 * fq + 8 * (u & 1));
+#pragma unroll
+    for (int u = 0; u < SNT_UNROLL; ++u) {
+      const int k0 = (pr + (u >> 1) * SNT_WAVES) * 64;  // wave-uniform
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+        if (!RANGED || (k0 >= kr.lo[nb] && k0 < kr.hi[nb])) b[u][nb] = *reinterpret_cast<const bf16x8_t*>(wrow[nb] + k0 + 16 * fq + 8 * (u & 1));
+    }
+#pragma unroll
+    for (int u = 0; u < SNT_UNROLL; ++u) {
+      const int k0 = (pr + (u >> 1) * SNT_WAVES) * 64;
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+        if (!RANGED || (k0 >= kr.lo[nb] && k0 < kr.hi[nb])) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[u], b[u][nb], acc[nb], 0, 0, 0);
+    }
+  }
+  // remaining k-steps (natural map), 32 k-values each
   const int nks = K >> 5;
-  int ks = wave;
-  for (; ks + (SNT_UNROLL - 1) * SNT_WAVES < nks; ks += SNT_UNROLL * SNT_WAVES) {
-    bf16x8_t a[SNT_UNROLL];
-#pragma unroll
-    for (int u = 0; u < SNT_UNROLL; ++u) a[u] = *reinterpret_cast<const bf16x8_t*>(xp + (ks + u * SNT_WAVES) * 32);
-#pragma unroll
-    for (int u = 0; u < SNT_UNROLL; ++u)
+  {
+    const int pr_done = rounds * (SNT_UNROLL / 2) * SNT_WAVES;  // pairs [0, pr_done) are finished
+    for (int ks = 2 * pr_done + wave; ks < nks; ks += SNT_WAVES) {
+      const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(xrow + ks * 32 + 8 * fq);
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
-        const bf16x8_t b = *reinterpret_cast<const bf16x8_t*>(wp[nb] + (ks + u * SNT_WAVES) * 32);
-        acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[u], b, acc[nb], 0, 0, 0);
+        if (RANGED && (ks * 32 < kr.lo[nb] || ks * 32 >= kr.hi[nb])) continue;
+        const bf16x8_t b = *reinterpret_cast<const bf16x8_t*>(wrow[nb] + ks * 32 + 8 * fq);
+        acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[nb], 0, 0, 0);
       }
-  }
-  for (; ks < nks; ks += SNT_WAVES) {
-    const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(xp + ks * 32);
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-      const bf16x8_t b = *reinterpret_cast<const bf16x8_t*>(wp[nb] + ks * 32);
-      acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[nb], 0, 0, 0);
     }
   }
 #pragma unroll
@@ -75,15 +101,25 @@ __global__ __launch_bounds__(SNT_WAVES * 64) void skinny_nt_kernel(const bf16_t*
 }
 
 // out: [M, 64] bf16 (row stride 64). K % 32 == 0, R <= 64.
+// kranges (host pointer, nullable): {lo_0, hi_0, ..., lo_3, hi_3}, multiples of 64: rows 16*nb..16*nb+15 of W are zero outside
+// k in [lo_nb, hi_nb) and those k-steps are skipped (block-diagonal W); null = dense W.
 extern "C" int llx_skinny_nt(const void* X, int64_t ldx, const void* W, int64_t ldw, void* out, int64_t M, int64_t K, int64_t R,
-                             hipStream_t stream) {
+                             const int32_t* kranges, hipStream_t stream) {
   LLX_REQUIRE(X && W && out, "llx_skinny_nt: null pointer");
   LLX_REQUIRE(M > 0 && K > 0 && K % 32 == 0 && R > 0 && R <= 64, "llx_skinny_nt: need K%%32==0 and 0<R<=64 (K=%lld R=%lld)", (long long)K, (long long)R);
   LLX_REQUIRE(ldx % 8 == 0 && ldw % 8 == 0 && ((uintptr_t)X | (uintptr_t)W) % 16 == 0 && (uintptr_t)out % 8 == 0, "llx_skinny_nt: alignment");
   const dim3 grid((unsigned)cdiv64(M, 16)), block(SNT_WAVES * 64);
   const int nb = (int)cdiv64(R, 16);
-#define L(N) hipLaunchKernelGGL(skinny_nt_kernel<N>, grid, block, 0, stream, (const bf16_t*)X, ldx, (const bf16_t*)W, ldw, (bf16_t*)out, (int)M, (int)K, (int)R)
-  if (nb == 1) L(1); else if (nb == 2) L(2); else L(4);
+  SkinnyRanges kr;
+  for (int i = 0; i < 4; ++i) {
+    kr.lo[i] = kranges ? kranges[2 * i] : 0;
+    kr.hi[i] = kranges ? kranges[2 * i + 1] : (int)K;
+    LLX_REQUIRE(kr.lo[i] % 64 == 0 && (kr.hi[i] % 64 == 0 || kr.hi[i] == (int)K) && kr.lo[i] >= 0 && kr.hi[i] <= (int)K,
+                "llx_skinny_nt: k range %d of a block-diagonal W must be a multiple of 64 inside [0, K]", i);
+  }
+#define L(N, RG) hipLaunchKernelGGL((skinny_nt_kernel<N, RG>), grid, block, 0, stream, (const bf16_t*)X, ldx, (const bf16_t*)W, ldw, (bf16_t*)out, (int)M, (int)K, (int)R, kr)
+  if (kranges) { if (nb == 1) L(1, true); else if (nb == 2) L(2, true); else L(4, true); }
+  else { if (nb == 1) L(1, false); else if (nb == 2) L(2, false); else L(4, false); }
 #undef L
   LLX_LAUNCH_CHECK("llx_skinny_nt");
   return LLX_OK;

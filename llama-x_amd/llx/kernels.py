@@ -5,8 +5,9 @@ torch's caching allocator; the C side never allocates or synchronises (include/l
 """
 from __future__ import annotations
 
+import ctypes
 import math
-from typing import Optional
+from typing import Optional, Sequence
 
 import torch
 from torch import Tensor
@@ -411,14 +412,19 @@ def ce_fwd_bwd(logits: Tensor, labels: Tensor, write_grad: bool) -> tuple[Tensor
 
 
 # ------------------------------------------------------------------------------------------------- skinny (LoRA)
-def skinny_nt(x: Tensor, w: Tensor) -> Tensor:
-    """[M,K] @ [R,K]^T -> [M,64] bf16, zero beyond column R."""
+def skinny_nt(x: Tensor, w: Tensor, kranges: Optional[Sequence[int]] = None) -> Tensor:
+    """[M,K] @ [R,K]^T -> [M,64] bf16, zero beyond column R.
+    kranges: (lo, hi) x 4, multiples of 64 - rows 16*nb..16*nb+15 of a block-diagonal w are zero outside k in [lo_nb, hi_nb)."""
     _chk_bf16(x, w)
     assert x.dim() == 2 and w.dim() == 2 and x.shape[1] == w.shape[1] and x.stride(1) == 1 and w.stride(1) == 1
     M, K = x.shape
     R = w.shape[0]
     out = torch.empty(M, SK_PAD, device=x.device, dtype=BF16)
-    L.check(_lib().llx_skinny_nt(L.ptr(x), x.stride(0), L.ptr(w), w.stride(0), L.ptr(out), M, K, R, L.stream()), "llx_skinny_nt")
+    kr = None
+    if kranges is not None:
+        assert len(kranges) == 8
+        kr = (ctypes.c_int32 * 8)(*[int(v) for v in kranges])
+    L.check(_lib().llx_skinny_nt(L.ptr(x), x.stride(0), L.ptr(w), w.stride(0), L.ptr(out), M, K, R, kr, L.stream()), "llx_skinny_nt")
     return out
 
 

@@ -262,6 +262,22 @@ class GroupPlan:
         return t
 
     # ---- backward: returns (dx, grads aligned with tensors())
+    def _kranges(self) -> Optional[list[int]]:
+        """k range of each 16-row block of the batched B^T (block-diagonal: member i owns rows r_off[i].. and k in
+        n_off[i]..n_off[i]+N_i); None when a boundary is not a multiple of 64 (the kernel then treats B^T as dense)."""
+        if getattr(self, "_kr", None) is None:
+            kr: list[int] = []
+            for nb in range(4):
+                lo, hi = None, None
+                for ro, r, no, n in zip(self.r_off, self.ranks, self.n_off, self.Ns):
+                    if r > 0 and ro < 16 * nb + 16 and ro + r > 16 * nb:
+                        lo = no if lo is None else min(lo, no)
+                        hi = no + n if hi is None else max(hi, no + n)
+                kr += [lo or 0, hi or 0] if lo is not None else [0, 0]
+            ok = all(v % 64 == 0 for v in kr)
+            self._kr = kr if ok else False
+        return self._kr or None
+
     def backward(self, dy: Tensor, x: Tensor, saved, needs: Sequence[bool], need_dx: bool, dx_out: Optional[Tensor] = None):
         if not self.fused:
             grads, dx, first = [], None, True
@@ -282,7 +298,7 @@ class GroupPlan:
             cnt = len(m.tensors())
             need.append([next(ni) for _ in range(cnt)])
         if self.R > 0:
-            u = K.skinny_nt(dy, bT)  # [M,64]: column block i = dy_i @ B_i
+            u = K.skinny_nt(dy, bT, self._kranges())  # [M,64]: column block i = dy_i @ B_i
             if any(nd[-2] for nd in need):
                 gA = torch.empty(self.R, self.K, device=dy.device, dtype=BF16)
                 K.skinny_tn(u, x, self.R, self.scale, gA, transpose_out=False)

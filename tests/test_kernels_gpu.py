@@ -157,6 +157,31 @@ def test_skinny_nt(K, cuda, M, Kd, R):
     assert out[:, R:].abs().sum() == 0
 
 
+@pytest.mark.parametrize("M,Ns,ranks", [(200, (1024, 512), (16, 16)), (512, (4096, 1024, 1024), (16, 16, 16)), (100, (640, 576), (8, 32)),
+                                        (64, (14336, 14336), (16, 16))])
+def test_skinny_nt_block_diagonal(K, cuda, M, Ns, ranks):
+    """The batched LoRA B^T of a fused linear group is block-diagonal; with the k ranges given the kernel skips the zero blocks
+    and must return exactly what it returns for the same matrix treated as dense."""
+    Kd, R = sum(Ns), sum(ranks)
+    w = torch.zeros(R, Kd, dtype=torch.bfloat16)
+    ro = no = 0
+    kr = []
+    spans = []
+    for n, r in zip(Ns, ranks):
+        w[ro : ro + r, no : no + n] = _bf(O.randn(f"w{no}", (r, n), 0.05))
+        spans.append((ro, r, no, n))
+        ro += r; no += n
+    for nb in range(4):
+        hit = [(no, no + n) for (ro, r, no, n) in spans if ro < 16 * nb + 16 and ro + r > 16 * nb]
+        kr += [min(h[0] for h in hit), max(h[1] for h in hit)] if hit else [0, 0]
+    x = _bf(O.randn("x", (M, Kd)))
+    dense = K.skinny_nt(x.to(cuda), w.to(cuda)).cpu()
+    sparse = K.skinny_nt(x.to(cuda), w.to(cuda), kr).cpu()
+    ref = x.float() @ w.float().T
+    torch.testing.assert_close(sparse[:, :R].float(), ref, atol=2 ** -7 * ref.abs().max().item(), rtol=2 ** -7)
+    assert torch.equal(dense, sparse)
+
+
 @pytest.mark.parametrize("M,N,R,tr", [(300, 512, 8, False), (4096, 4096, 16, True), (256, 128, 16, False), (1000, 1792, 40, True)])
 def test_skinny_tn(K, cuda, M, N, R, tr):
     u = torch.zeros(M, 64, dtype=torch.bfloat16)
