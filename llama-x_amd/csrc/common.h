@@ -89,3 +89,26 @@ __device__ __forceinline__ float block_max(float v, float* red) {
 }
 
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---- SwiGLU pieces shared by the element-wise kernels and the GEMM epilogue (h = silu(g) * u, modelling/llama.py:150)
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
+// 8 packed bf16 elements: dg = (dh*u rounded) * silu'(g), du = dh * (silu(g) rounded)  -- the roundings autograd's bf16 graph makes
+__device__ __forceinline__ void swiglu_bwd8(const u32x4_t& dv, const u32x4_t& gv, const u32x4_t& uv, u32x4_t& og, u32x4_t& ou) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float dgs[2], dus[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const float gg = p ? bfhi(gv[e]) : bflo(gv[e]);
+      const float uu = p ? bfhi(uv[e]) : bflo(uv[e]);
+      const float dd = p ? bfhi(dv[e]) : bflo(dv[e]);
+      const float sg = sigmoidf_(gg);
+      const float silu = bf2f(f2bf(gg * sg));
+      dus[p] = dd * silu;
+      const float ds = bf2f(f2bf(dd * uu));
+      dgs[p] = ds * (sg * (1.f + gg * (1.f - sg)));
+    }
+    og[e] = pack_bf2(dgs[0], dgs[1]);
+    ou[e] = pack_bf2(dus[0], dus[1]);
+  }
+}

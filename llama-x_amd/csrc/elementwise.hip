@@ -93,7 +93,6 @@ extern "C" int llx_rope(const void* x, int64_t x_sb, int64_t x_ss, void* y, int6
 
 // ------------------------------------------------------------------------------------------ SwiGLU
 // silu(w1 x) * w3 x (modelling/llama.py:152) with eager rounding points: s = bf16(silu(g)); h = bf16(s * u).
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
 
 __global__ void swiglu_fwd_kernel(const bf16_t* __restrict__ g, const bf16_t* __restrict__ u, bf16_t* __restrict__ h, int64_t rows, int cols,
                                   int64_t g_ld, int64_t u_ld, int64_t h_ld) {
@@ -127,23 +126,7 @@ __global__ void swiglu_bwd_kernel(const bf16_t* __restrict__ dh, const bf16_t* _
   const u32x4_t gv = *reinterpret_cast<const u32x4_t*>(g + r * g_ld + c);
   const u32x4_t uv = *reinterpret_cast<const u32x4_t*>(u + r * u_ld + c);
   u32x4_t og, ou;
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    float dgs[2], dus[2];
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      const float gg = p ? bfhi(gv[e]) : bflo(gv[e]);
-      const float uu = p ? bfhi(uv[e]) : bflo(uv[e]);
-      const float dd = p ? bfhi(dv[e]) : bflo(dv[e]);
-      const float sg = sigmoidf_(gg);
-      const float silu = bf2f(f2bf(gg * sg));
-      dus[p] = dd * silu;
-      const float ds = bf2f(f2bf(dd * uu));
-      dgs[p] = ds * (sg * (1.f + gg * (1.f - sg)));
-    }
-    og[e] = pack_bf2(dgs[0], dgs[1]);
-    ou[e] = pack_bf2(dus[0], dus[1]);
-  }
+  swiglu_bwd8(dv, gv, uv, og, ou);
   *reinterpret_cast<u32x4_t*>(dg + r * dg_ld + c) = og;
   *reinterpret_cast<u32x4_t*>(du + r * du_ld + c) = ou;
 }

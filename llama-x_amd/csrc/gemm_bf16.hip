@@ -22,7 +22,7 @@
 #define EPI_ROW_BYTES 528                       // 512 B of bf16 + 16 B pad (bank spread for the ds_write_b64)
 #define GEMM_LDS_BYTES (256 * EPI_ROW_BYTES)    // 135168 >= 2 * STAGE_BYTES
 
-enum { EPI_NONE = 0, EPI_RESIDUAL = 1, EPI_BIAS = 2, EPI_BIAS_GELU = 3, EPI_COLSCALE = 4, EPI_ROWCOLSCALE = 5 };
+enum { EPI_NONE = 0, EPI_RESIDUAL = 1, EPI_BIAS = 2, EPI_BIAS_GELU = 3, EPI_COLSCALE = 4, EPI_ROWCOLSCALE = 5, EPI_SWIGLU_BWD = 6 };
 
 struct GemmArgs {
   const bf16_t* A; const bf16_t* B; bf16_t* C;
@@ -309,6 +309,15 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const GemmArgs g) {
           }
           v[e] = pack_bf2(lo, hi);
         }
+      } else if constexpr (EPI == EPI_SWIGLU_BWD) {
+        // the product is dh = dL/d(silu(g)*u); what leaves the kernel is dg | du (SwiGLU backward fused: dh never reaches HBM).
+        // v holds dh rounded to bf16 exactly as the stand-alone GEMM would have stored it.
+        const u32x4_t gv = *reinterpret_cast<const u32x4_t*>(g.E + (int64_t)gm * g.lde + gn);
+        const u32x4_t uv = *reinterpret_cast<const u32x4_t*>(g.E + (int64_t)gm * g.lde + g.N + gn);
+        u32x4_t og, ou;
+        swiglu_bwd8(v, gv, uv, og, ou);
+        *reinterpret_cast<u32x4_t*>(g.C + (int64_t)gm * g.ldc + g.N + gn) = ou;
+        v = og;
       } else if constexpr (EPI == EPI_COLSCALE) {
         // weight-only int8: (x @ W_i8^T) rounded to bf16, then * scale[n] (subclasses/int8.py:118)
         u32x4_t s = *reinterpret_cast<const u32x4_t*>(g.E + gn);
@@ -357,7 +366,8 @@ static int launch_gemm(const GemmArgs& a, hipStream_t stream) {
 
 // C[M,N] = A[M,K].B[N,K]^T (+ A2[M,K2].B2[N,K2]^T), bf16 in/out, fp32 accumulate.
 // ld* are row strides in elements.  K and K2 must be multiples of 64, N a multiple of 8, all pointers and row
-// strides 16-byte aligned.  epilogue: 0 none | 1 +E[M,N] (ld=lde) | 2 +bias E[N] | 3 gelu(+bias) | 4 *colscale E[N].
+// strides 16-byte aligned.  epilogue: 0 none | 1 +E[M,N] (ld=lde) | 2 +bias E[N] | 3 gelu(+bias) | 4 *colscale E[N] |
+// 6 SwiGLU backward (E = gate|up [M,2N], C = dg|du [M,2N]).
 extern "C" int llx_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M,
                                 int64_t N, int64_t K, const void* A2, int64_t lda2, const void* B2, int64_t ldb2, int64_t K2,
                                 int epilogue, const void* E, int64_t lde, hipStream_t stream) {
@@ -370,7 +380,8 @@ extern "C" int llx_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64
   LLX_REQUIRE(K2 == 0 || (A2 && B2 && lda2 % 8 == 0 && ldb2 % 8 == 0 && ((uintptr_t)A2 | (uintptr_t)B2) % 16 == 0),
               "llx_gemm_nt_bf16: bad K-extension operands");
   LLX_REQUIRE(epilogue == EPI_NONE || (E && (uintptr_t)E % 16 == 0), "llx_gemm_nt_bf16: epilogue operand missing/unaligned");
-  LLX_REQUIRE(epilogue != EPI_RESIDUAL || lde % 8 == 0, "llx_gemm_nt_bf16: residual stride must be a multiple of 8");
+  LLX_REQUIRE((epilogue != EPI_RESIDUAL && epilogue != EPI_SWIGLU_BWD) || lde % 8 == 0, "llx_gemm_nt_bf16: residual / gate|up stride must be a multiple of 8");
+  LLX_REQUIRE(epilogue != EPI_SWIGLU_BWD || (lde >= 2 * N && ldc >= 2 * N), "llx_gemm_nt_bf16: the SwiGLU-backward epilogue reads E[M,2N] (gate|up) and writes C[M,2N] (dg|du)");
   LLX_REQUIRE(M < (1 << 30) && N < (1 << 30) && K < (1 << 30), "llx_gemm_nt_bf16: dimension too large");
   LLX_REQUIRE(M * lda * 2 < (int64_t)4294967296 && N * ldb * 2 < (int64_t)4294967296, "llx_gemm_nt_bf16: operand larger than 4 GiB (32-bit tile offsets)");
   GemmArgs a;
@@ -385,6 +396,7 @@ extern "C" int llx_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64
     case EPI_BIAS: return launch_gemm<EPI_BIAS>(a, stream);
     case EPI_BIAS_GELU: return launch_gemm<EPI_BIAS_GELU>(a, stream);
     case EPI_COLSCALE: return launch_gemm<EPI_COLSCALE>(a, stream);
+    case EPI_SWIGLU_BWD: return launch_gemm<EPI_SWIGLU_BWD>(a, stream);
     default: llx_set_error("llx_gemm_nt_bf16: unknown epilogue %d", epilogue); return LLX_ERR_UNSUPPORTED;
   }
 }

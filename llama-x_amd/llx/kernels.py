@@ -16,6 +16,7 @@ from . import _lib as L
 
 BF16 = torch.bfloat16
 EPI_NONE, EPI_RESIDUAL, EPI_BIAS, EPI_BIAS_GELU, EPI_COLSCALE = 0, 1, 2, 3, 4
+EPI_SWIGLU_BWD = 6  # the product is dh; e = gate|up [M, 2N]; out = dg|du [M, 2N] (dh itself is not stored)
 SK_PAD = 64
 GEMM_TRACE = None  # bench.py sets this to a list to collect (start_event, end_event, algorithmic_flops) per GEMM launch
 
@@ -81,9 +82,12 @@ def gemm_nt(a: Tensor, b: Tensor, *, out: Optional[Tensor] = None, a2: Optional[
     assert a.stride(1) == 1 and b.stride(1) == 1
     M, K = a.shape
     N = b.shape[0]
-    if out is None:
-        out = torch.empty(M, N, device=a.device, dtype=BF16)
-    assert out.shape == (M, N) and out.stride(1) == 1
+    if epilogue == EPI_SWIGLU_BWD:
+        assert out is not None and e is not None and out.shape == (M, 2 * N) and e.shape == (M, 2 * N) and out.stride(1) == 1 and e.stride(1) == 1
+    else:
+        if out is None:
+            out = torch.empty(M, N, device=a.device, dtype=BF16)
+        assert out.shape == (M, N) and out.stride(1) == 1
     K2 = 0
     if a2 is not None:
         assert b2 is not None and a2.shape[0] == M and b2.shape[0] == N and a2.shape[1] == b2.shape[1]
@@ -92,6 +96,8 @@ def gemm_nt(a: Tensor, b: Tensor, *, out: Optional[Tensor] = None, a2: Optional[
     lde = 0
     if epilogue == EPI_RESIDUAL:
         assert e is not None and e.shape == (M, N) and e.stride(1) == 1
+        lde = e.stride(0)
+    elif epilogue == EPI_SWIGLU_BWD:
         lde = e.stride(0)
     elif epilogue != EPI_NONE:
         assert e is not None and e.shape == (N,) and e.is_contiguous()

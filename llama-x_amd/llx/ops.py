@@ -265,6 +265,8 @@ class GroupPlan:
     def _kranges(self) -> Optional[list[int]]:
         """k range of each 16-row block of the batched B^T (block-diagonal: member i owns rows r_off[i].. and k in
         n_off[i]..n_off[i]+N_i); None when a boundary is not a multiple of 64 (the kernel then treats B^T as dense)."""
+        if getattr(self, "_kr", None) is None and len(self.members) == 1:
+            self._kr = False  # a single member's B^T is dense
         if getattr(self, "_kr", None) is None:
             kr: list[int] = []
             for nb in range(4):
@@ -278,7 +280,10 @@ class GroupPlan:
             self._kr = kr if ok else False
         return self._kr or None
 
-    def backward(self, dy: Tensor, x: Tensor, saved, needs: Sequence[bool], need_dx: bool, dx_out: Optional[Tensor] = None):
+    def backward(self, dy: Tensor, x: Tensor, saved, needs: Sequence[bool], need_dx: bool, dx_out: Optional[Tensor] = None,
+                 swiglu: Optional[tuple[Tensor, Tensor]] = None):
+        """swiglu = (gate|up activations [M, 2K], dg|du output [M, 2K]): the data gradient of this linear is the gradient of
+        silu(g)*u, and the dgrad GEMM applies the SwiGLU backward in its epilogue (returns the dg|du tensor instead of dx)."""
         if not self.fused:
             grads, dx, first = [], None, True
             ni = 0
@@ -317,7 +322,10 @@ class GroupPlan:
         dx = None
         if need_dx:
             g = K.scale(dy, colscale=self.scale_cat()) if self.int8 else dy  # (g * scale) rounded (subclasses/int8.py:127)
-            dx = K.gemm_nt(g, self.wt_cat(), out=dx_out, a2=u, b2=a2t if self.R > 0 else None)
+            if swiglu is not None:
+                dx = K.gemm_nt(g, self.wt_cat(), out=swiglu[1], a2=u, b2=a2t if self.R > 0 else None, epilogue=K.EPI_SWIGLU_BWD, e=swiglu[0])
+            else:
+                dx = K.gemm_nt(g, self.wt_cat(), out=dx_out, a2=u, b2=a2t if self.R > 0 else None)
         return dx, grads
 
 
@@ -513,9 +521,12 @@ class MLPBlockFn(Function):
         needs = list(ctx.needs_input_grad[3:])
         n_13 = len(meta.w13.tensors())
         n13, n2 = needs[:n_13], needs[n_13:]
-        dh, g_2 = meta.w2.backward(dy2, h, t2, n2, True)
         dgu = torch.empty(T, 2 * I, device=x.device, dtype=BF16)
-        K.swiglu_bwd(dh, gu[:, :I], gu[:, I:], dgu[:, :I], dgu[:, I:])
+        if meta.w2.fused:  # dh = dy.W2 (+LoRA) never reaches HBM: the dgrad GEMM's epilogue turns it into dg | du
+            _, g_2 = meta.w2.backward(dy2, h, t2, n2, True, swiglu=(gu, dgu))
+        else:
+            dh, g_2 = meta.w2.backward(dy2, h, t2, n2, True)
+            K.swiglu_bwd(dh, gu[:, :I], gu[:, I:], dgu[:, :I], dgu[:, I:])
         need_dx = ctx.needs_input_grad[0]
         need_dxn = need_dx or (meta.fuse_norm and ctx.needs_input_grad[1])
         dxn = torch.empty_like(x2) if need_dxn else None

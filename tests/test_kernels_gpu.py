@@ -69,6 +69,22 @@ def test_gemm_nt(K, cuda, M, N, K_, K2, epi):
     torch.testing.assert_close(c.cpu().float(), ref, atol=2 ** -7 * ref.abs().max().item(), rtol=2 ** -7)
 
 
+@pytest.mark.parametrize("M,I,D,K2", [(512, 768, 256, 64), (300, 1280, 128, 0)])
+def test_gemm_swiglu_bwd_epilogue(K, cuda, M, I, D, K2):
+    """dgrad of w2 with the SwiGLU backward in the epilogue == the same GEMM followed by the stand-alone swiglu_bwd, bit for bit."""
+    dy = _bf(O.randn("dy", (M, D))).to(cuda)
+    wt = _bf(O.randn("wt", (I, D), 0.05)).to(cuda)          # W2^T image: dh = dy @ wt^T
+    a2 = _bf(O.randn("a2", (M, K2))).to(cuda) if K2 else None
+    b2 = _bf(O.randn("b2", (I, K2), 0.05)).to(cuda) if K2 else None
+    gu = _bf(O.randn("gu", (M, 2 * I))).to(cuda)
+    dh = K.gemm_nt(dy, wt, a2=a2, b2=b2)
+    ref = torch.empty(M, 2 * I, device=cuda, dtype=torch.bfloat16)
+    K.swiglu_bwd(dh, gu[:, :I], gu[:, I:], ref[:, :I], ref[:, I:])
+    out = torch.empty(M, 2 * I, device=cuda, dtype=torch.bfloat16)
+    K.gemm_nt(dy, wt, out=out, a2=a2, b2=b2, epilogue=K.EPI_SWIGLU_BWD, e=gu)
+    assert torch.equal(out, ref)
+
+
 def test_gemm_rejects_bad_shapes(K, cuda):
     from llx._lib import LlxError
 
