@@ -117,7 +117,9 @@ int llx_skinny_nt(const void* X, int64_t ldx, const void* W, int64_t ldw, void* 
                   const int32_t* kranges /* host, nullable: {lo,hi} x 4 per 16 rows of a block-diagonal W */, llx_stream_t s);
 int64_t llx_skinny_tn_workspace_bytes(int64_t M, int64_t N, int64_t R);
 int llx_skinny_tn(const void* U, const void* Y, int64_t ldy, void* out, int64_t out_ld, int64_t M, int64_t N, int64_t R, float scale,
-                  int transpose_out, int accumulate, void* workspace, llx_stream_t s);
+                  int transpose_out, int accumulate, void* workspace,
+                  const int32_t* segs /* host, nullable: {n_lo, n_hi, r_lo, r_hi} per member of a fused group; member blocks are
+                                         then written one after another as contiguous [n, r] matrices */, int seg_count, llx_stream_t s);
 int llx_pad64(const void* in, int64_t ld, void* out, int64_t R, int64_t C, float scale, int transpose, llx_stream_t s);
 int llx_lora_group_pack(const void* const* lora_a, const void* const* lora_b, const int64_t* Ns, const int64_t* ranks, int nm, int64_t K,
                         float scale, void* a_cat, void* b2, void* bT, void* a2t, llx_stream_t s);  /* all four images, one launch (host arrays) */

@@ -142,9 +142,15 @@ __device__ __forceinline__ bf16x8_t tr16_frag(const char* tile, int rowbytes, in
   return __builtin_bit_cast(bf16x8_t, v);
 }
 
+// Member segments of a fused linear group's dB^T = dy^T.t: member i owns output rows n in [n_lo, n_hi) and columns r in
+// [r_lo, r_hi) (block-diagonal; everything else of the [N, R] product is never read).  With segments the main kernel skips the
+// 16-row blocks rb whose members do not meet the column tile, and the reduce writes each member's block as its own contiguous
+// [n_hi - n_lo, r_hi - r_lo] matrix at out + off (offsets in member order), so no slicing copy follows.
+struct TnSegs { int n_lo[4], n_hi[4], r_lo[4], r_hi[4]; int64_t off[4]; int count; int rb_lo[4], rb_hi[4]; };
+
 template <int NB>
 __global__ __launch_bounds__(256) void skinny_tn_kernel(const bf16_t* __restrict__ U, const bf16_t* __restrict__ Y, int64_t ldy,
-                                                        float* __restrict__ partial, int M, int N, int rows_per_split) {
+                                                        float* __restrict__ partial, int M, int N, int rows_per_split, TnSegs sg) {
   __shared__ __attribute__((aligned(16))) char sY[TN_MS * TN_YROW];
   __shared__ __attribute__((aligned(16))) char sU[TN_MS * TN_UROW];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -185,7 +191,8 @@ __global__ __launch_bounds__(256) void skinny_tn_kernel(const bf16_t* __restrict
     for (int cb = 0; cb < 4; ++cb) {
       const bf16x8_t b = tr16_frag(sY, TN_YROW, wave * 64 + cb * 16, lane);
 #pragma unroll
-      for (int rb = 0; rb < NB; ++rb) acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[rb], b, acc[rb][cb], 0, 0, 0);
+      for (int rb = 0; rb < NB; ++rb)
+        if (n0 + TN_NT > sg.rb_lo[rb] && n0 < sg.rb_hi[rb]) acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[rb], b, acc[rb][cb], 0, 0, 0);
     }
   }
   // D[row = r][col = n]: lane -> n = lane&15, r = (lane>>4)*4 + e
@@ -195,7 +202,7 @@ __global__ __launch_bounds__(256) void skinny_tn_kernel(const bf16_t* __restrict
 #pragma unroll
     for (int cb = 0; cb < 4; ++cb) {
       const int n = n0 + wave * 64 + cb * 16 + fr;
-      if (n < N) {
+      if (n < N && n0 + TN_NT > sg.rb_lo[rb] && n0 < sg.rb_hi[rb]) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) partial[((int64_t)split * (NB * 16) + rb * 16 + fq * 4 + e) * N + n] = acc[rb][cb][e];
       }
@@ -216,6 +223,27 @@ __global__ void skinny_tn_reduce_kernel(const float* __restrict__ partial, bf16_
   *dst = f2bf(s);
 }
 
+// segment form: thread -> (member, n, r); out + off[member] is that member's contiguous [n_hi - n_lo, r_hi - r_lo] gradient
+__global__ void skinny_tn_reduce_segs_kernel(const float* __restrict__ partial, bf16_t* __restrict__ out, int nsplit, int RP, int N, float scale,
+                                             int accumulate, TnSegs sg) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int m = 0;
+  for (; m < sg.count; ++m) {
+    const int64_t cnt = (int64_t)(sg.n_hi[m] - sg.n_lo[m]) * (sg.r_hi[m] - sg.r_lo[m]);
+    if (idx < cnt) break;
+    idx -= cnt;
+  }
+  if (m >= sg.count) return;
+  const int rw = sg.r_hi[m] - sg.r_lo[m];
+  const int n = sg.n_lo[m] + (int)(idx / rw), r = sg.r_lo[m] + (int)(idx % rw);
+  float s = 0.f;
+  for (int p = 0; p < nsplit; ++p) s += partial[((int64_t)p * RP + r) * N + n];
+  s *= scale;
+  bf16_t* dst = out + sg.off[m] + idx;
+  if (accumulate) s += bf2f(*dst);
+  *dst = f2bf(s);
+}
+
 static int tn_splits(int64_t M, int64_t N) {
   const int64_t ntiles = cdiv64(N, TN_NT);
   int64_t want = cdiv64(512, ntiles);           // ~2 blocks per CU
@@ -230,19 +258,50 @@ extern "C" int64_t llx_skinny_tn_workspace_bytes(int64_t M, int64_t N, int64_t R
 }
 
 // U: [M, 64] bf16 (row stride 64; columns >= R ignored), Y: [M, N] (row stride ldy).  workspace as above.
+// segs (host pointer, nullable): up to 4 members {n_lo, n_hi, r_lo, r_hi} (n bounds multiples of 256 or N), seg_count of them:
+// only those blocks of the [N, R] product are computed, and member i's block is written transposed-out as a contiguous
+// [n_hi - n_lo, r_hi - r_lo] matrix at out + sum_{j<i} size_j (out_ld and transpose_out are ignored).
 extern "C" int llx_skinny_tn(const void* U, const void* Y, int64_t ldy, void* out, int64_t out_ld, int64_t M, int64_t N, int64_t R,
-                             float scale, int transpose_out, int accumulate, void* workspace, hipStream_t stream) {
+                             float scale, int transpose_out, int accumulate, void* workspace, const int32_t* segs, int seg_count,
+                             hipStream_t stream) {
   LLX_REQUIRE(U && Y && out && workspace, "llx_skinny_tn: null pointer");
   LLX_REQUIRE(M > 0 && N > 0 && N % 8 == 0 && R > 0 && R <= 64 && ldy % 8 == 0, "llx_skinny_tn: need N%%8==0, ldy%%8==0, 0<R<=64");
   LLX_REQUIRE(((uintptr_t)U | (uintptr_t)Y) % 16 == 0, "llx_skinny_tn: unaligned pointer");
   const int nsplit = tn_splits(M, N);
   int rows_per_split = (int)cdiv64(cdiv64(M, nsplit), TN_MS) * TN_MS;
   const int nb = (int)cdiv64(R, 16);
+  TnSegs sg;
+  sg.count = 0;
+  for (int rb = 0; rb < 4; ++rb) { sg.rb_lo[rb] = 0; sg.rb_hi[rb] = (int)N; }
+  int64_t total = 0;
+  if (segs) {
+    LLX_REQUIRE(seg_count >= 1 && seg_count <= 4, "llx_skinny_tn: 1..4 segments");
+    for (int rb = 0; rb < 4; ++rb) { sg.rb_lo[rb] = (int)N; sg.rb_hi[rb] = 0; }
+    for (int i = 0; i < seg_count; ++i) {
+      sg.n_lo[i] = segs[4 * i]; sg.n_hi[i] = segs[4 * i + 1]; sg.r_lo[i] = segs[4 * i + 2]; sg.r_hi[i] = segs[4 * i + 3];
+      LLX_REQUIRE(sg.n_lo[i] >= 0 && sg.n_lo[i] < sg.n_hi[i] && sg.n_hi[i] <= N && sg.r_lo[i] >= 0 && sg.r_lo[i] < sg.r_hi[i] && sg.r_hi[i] <= R,
+                  "llx_skinny_tn: bad segment %d", i);
+      LLX_REQUIRE(sg.n_lo[i] % TN_NT == 0 && (sg.n_hi[i] % TN_NT == 0 || sg.n_hi[i] == N), "llx_skinny_tn: segment %d: n bounds must be multiples of 256", i);
+      sg.off[i] = total;
+      total += (int64_t)(sg.n_hi[i] - sg.n_lo[i]) * (sg.r_hi[i] - sg.r_lo[i]);
+      for (int rb = sg.r_lo[i] / 16; rb <= (sg.r_hi[i] - 1) / 16; ++rb) {
+        if (sg.n_lo[i] < sg.rb_lo[rb]) sg.rb_lo[rb] = sg.n_lo[i];
+        if (sg.n_hi[i] > sg.rb_hi[rb]) sg.rb_hi[rb] = sg.n_hi[i];
+      }
+    }
+    sg.count = seg_count;
+  }
   const dim3 grid((unsigned)cdiv64(N, TN_NT), (unsigned)nsplit), block(256);
-#define L(NBV) hipLaunchKernelGGL(skinny_tn_kernel<NBV>, grid, block, 0, stream, (const bf16_t*)U, (const bf16_t*)Y, ldy, (float*)workspace, (int)M, (int)N, rows_per_split)
+#define L(NBV) hipLaunchKernelGGL(skinny_tn_kernel<NBV>, grid, block, 0, stream, (const bf16_t*)U, (const bf16_t*)Y, ldy, (float*)workspace, (int)M, (int)N, rows_per_split, sg)
   if (nb == 1) L(1); else if (nb == 2) L(2); else if (nb == 3) L(3); else L(4);
 #undef L
   LLX_LAUNCH_CHECK("llx_skinny_tn");
+  if (segs) {
+    hipLaunchKernelGGL(skinny_tn_reduce_segs_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, stream, (const float*)workspace, (bf16_t*)out,
+                       nsplit, nb * 16, (int)N, scale, accumulate, sg);
+    LLX_LAUNCH_CHECK("llx_skinny_tn(reduce segments)");
+    return LLX_OK;
+  }
   hipLaunchKernelGGL(skinny_tn_reduce_kernel, dim3((unsigned)cdiv64(R * N, 256)), dim3(256), 0, stream, (const float*)workspace, (bf16_t*)out,
                      out_ld, nsplit, nb * 16, (int)R, (int)N, scale, transpose_out, accumulate);
   LLX_LAUNCH_CHECK("llx_skinny_tn(reduce)");

@@ -434,13 +434,22 @@ def skinny_nt(x: Tensor, w: Tensor, kranges: Optional[Sequence[int]] = None) -> 
     return out
 
 
-def skinny_tn(u: Tensor, y: Tensor, R: int, scale_: float, out: Tensor, transpose_out: bool, accumulate: bool = False) -> Tensor:
-    """out ([R,N], or [N,R] when transpose_out) (+)= scale * u[:, :R]^T @ y, u [M,64], y [M,N]."""
+def skinny_tn(u: Tensor, y: Tensor, R: int, scale_: float, out: Tensor, transpose_out: bool, accumulate: bool = False,
+              segs: Optional[Sequence[tuple[int, int, int, int]]] = None) -> Tensor:
+    """out ([R,N], or [N,R] when transpose_out) (+)= scale * u[:, :R]^T @ y, u [M,64], y [M,N].
+    segs: members (n_lo, n_hi, r_lo, r_hi) of a fused group (block-diagonal product): out is then a flat buffer that receives the
+    members' [n, r] blocks one after another, each contiguous."""
     _chk_bf16(u, y, out)
     M, N = y.shape
-    assert u.shape == (M, SK_PAD) and u.is_contiguous() and y.stride(1) == 1 and out.stride(1) == 1
-    assert out.shape == ((N, R) if transpose_out else (R, N))
+    assert u.shape == (M, SK_PAD) and u.is_contiguous() and y.stride(1) == 1 and out.stride(-1) == 1
+    sp, ns = None, 0
+    if segs is not None:
+        ns = len(segs)
+        assert 1 <= ns <= 4 and out.is_contiguous() and out.numel() == sum((b - a) * (d - c) for a, b, c, d in segs)
+        sp = (ctypes.c_int32 * (4 * ns))(*[int(v) for sgm in segs for v in sgm])
+    else:
+        assert out.shape == ((N, R) if transpose_out else (R, N))
     ws = torch.empty(_lib().llx_skinny_tn_workspace_bytes(M, N, R), device=y.device, dtype=torch.uint8)
-    L.check(_lib().llx_skinny_tn(L.ptr(u), L.ptr(y), y.stride(0), L.ptr(out), out.stride(0), M, N, R, scale_, int(transpose_out),
-                                 int(accumulate), L.ptr(ws), L.stream()), "llx_skinny_tn")
+    L.check(_lib().llx_skinny_tn(L.ptr(u), L.ptr(y), y.stride(0), L.ptr(out), out.stride(0) if out.dim() == 2 else 0, M, N, R, scale_,
+                                 int(transpose_out), int(accumulate), L.ptr(ws), sp, ns, L.stream()), "llx_skinny_tn")
     return out

@@ -262,6 +262,14 @@ class GroupPlan:
         return t
 
     # ---- backward: returns (dx, grads aligned with tensors())
+    def _tn_segs(self) -> Optional[list[tuple[int, int, int, int]]]:
+        """(n_lo, n_hi, r_lo, r_hi) of every adapted member for the segment form of skinny_tn; None when it does not apply."""
+        if getattr(self, "_segs", None) is None:
+            segs = [(no, no + n, ro, ro + r) for ro, r, no, n in zip(self.r_off, self.ranks, self.n_off, self.Ns) if r > 0]
+            ok = 1 <= len(segs) <= 4 and all(a % 256 == 0 and (b % 256 == 0 or b == self.N) for a, b, _, _ in segs)
+            self._segs = segs if ok else False
+        return self._segs or None
+
     def _kranges(self) -> Optional[list[int]]:
         """k range of each 16-row block of the batched B^T (block-diagonal: member i owns rows r_off[i].. and k in
         n_off[i]..n_off[i]+N_i); None when a boundary is not a multiple of 64 (the kernel then treats B^T as dense)."""
@@ -297,6 +305,7 @@ class GroupPlan:
             return dx, grads
         t, bT, a2t = saved if saved is not None else (None, None, None)
         u = gA = gBt = None
+        gB_views: Optional[list[Optional[Tensor]]] = None
         ni = iter(needs)
         need = []
         for m in self.members:
@@ -308,9 +317,19 @@ class GroupPlan:
                 gA = torch.empty(self.R, self.K, device=dy.device, dtype=BF16)
                 K.skinny_tn(u, x, self.R, self.scale, gA, transpose_out=False)
             if any(nd[-1] for nd in need):
-                gBt = torch.empty(self.N, self.R, device=dy.device, dtype=BF16)
-                K.skinny_tn(t, dy, self.R, self.scale, gBt, transpose_out=True)
+                segs = self._tn_segs()
+                if segs is not None:  # each member's dB lands in its own contiguous block of one flat buffer: no slicing copies
+                    flat = torch.empty(sum((b - a) * (d - c) for a, b, c, d in segs), device=dy.device, dtype=BF16)
+                    K.skinny_tn(t, dy, self.R, self.scale, flat, transpose_out=True, segs=segs)
+                    gB_views, off = [], 0
+                    for m_, (a, b, c, d) in zip([m for m in self.members if m.rank > 0], segs):
+                        gB_views.append(flat[off : off + (b - a) * (d - c)].view(b - a, d - c))
+                        off += (b - a) * (d - c)
+                else:
+                    gBt = torch.empty(self.N, self.R, device=dy.device, dtype=BF16)
+                    K.skinny_tn(t, dy, self.R, self.scale, gBt, transpose_out=True)
         grads: list[Optional[Tensor]] = []
+        gb_i = 0
         for m, nd, ro, no, n in zip(self.members, need, self.r_off, self.n_off, self.Ns):
             j = 0
             if not m.int8:
@@ -318,7 +337,11 @@ class GroupPlan:
                 j += 1
             if m.rank > 0:
                 grads.append(gA[ro : ro + m.rank] if nd[j] else None)
-                grads.append(gBt[no : no + n, ro : ro + m.rank].contiguous() if nd[j + 1] else None)
+                if gB_views is not None:
+                    grads.append(gB_views[gb_i] if nd[j + 1] else None)
+                    gb_i += 1
+                else:
+                    grads.append(gBt[no : no + n, ro : ro + m.rank].contiguous() if nd[j + 1] else None)
         dx = None
         if need_dx:
             g = K.scale(dy, colscale=self.scale_cat()) if self.int8 else dy  # (g * scale) rounded (subclasses/int8.py:127)

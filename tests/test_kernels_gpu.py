@@ -210,6 +210,29 @@ def test_skinny_tn(K, cuda, M, N, R, tr):
     torch.testing.assert_close(got, ref, atol=2 ** -7 * ref.abs().max().item(), rtol=2 ** -7)
 
 
+@pytest.mark.parametrize("M,Ns,ranks", [(500, (512, 256), (16, 16)), (1024, (4096, 1024, 1024), (16, 16, 16)), (300, (768, 512), (8, 32))])
+def test_skinny_tn_member_segments(K, cuda, M, Ns, ranks):
+    """dB^T of a fused group: only the members' diagonal blocks are produced, each as its own contiguous [n, r] matrix, and they
+    equal the corresponding slices of the full product bit for bit."""
+    N, R = sum(Ns), sum(ranks)
+    u = torch.zeros(M, 64, dtype=torch.bfloat16)
+    u[:, :R] = _bf(O.randn("u", (M, R)))
+    y = _bf(O.randn("y", (M, N)))
+    full = torch.empty(N, R, device=cuda, dtype=torch.bfloat16)
+    K.skinny_tn(u.to(cuda), y.to(cuda), R, 0.5, full, True)
+    segs, no, ro = [], 0, 0
+    for n, r in zip(Ns, ranks):
+        segs.append((no, no + n, ro, ro + r)); no += n; ro += r
+    flat = torch.empty(sum(n * r for n, r in zip(Ns, ranks)), device=cuda, dtype=torch.bfloat16)
+    K.skinny_tn(u.to(cuda), y.to(cuda), R, 0.5, flat, True, segs=segs)
+    off = 0
+    for (a, b, c, d) in segs:
+        blk = flat[off : off + (b - a) * (d - c)].view(b - a, d - c); off += (b - a) * (d - c)
+        assert torch.equal(blk, full[a:b, c:d])
+    ref = 0.5 * (y.float().T @ u[:, :R].float())
+    torch.testing.assert_close(full.cpu().float(), ref, atol=2 ** -7 * ref.abs().max().item(), rtol=2 ** -7)
+
+
 def test_transpose_and_widen(K, cuda):
     x = _bf(O.randn("x", (300, 520)))
     assert torch.equal(K.transpose(x.to(cuda)).cpu(), x.T.contiguous())
