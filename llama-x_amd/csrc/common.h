@@ -91,7 +91,8 @@ __device__ __forceinline__ float block_max(float v, float* red) {
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // ---- SwiGLU pieces shared by the element-wise kernels and the GEMM epilogue (h = silu(g) * u, modelling/llama.py:150)
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
+// v_rcp_f32 (1 ulp) instead of the IEEE divide sequence: the result is rounded to bf16 right after
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
 // 8 packed bf16 elements: dg = (dh*u rounded) * silu'(g), du = dh * (silu(g) rounded)  -- the roundings autograd's bf16 graph makes
 __device__ __forceinline__ void swiglu_bwd8(const u32x4_t& dv, const u32x4_t& gv, const u32x4_t& uv, u32x4_t& og, u32x4_t& ou) {
 #pragma unroll
