@@ -44,6 +44,8 @@ int llx_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* r
  *      epilogue: 0 none | 1 + E[M,N] (ld = lde) | 2 + bias E[N] | 3 gelu(+bias E[N]) | 4 * colscale E[N]
  *      (weight-only int8, subclasses/int8.py:118) | 6 SwiGLU backward: the product is dh = dL/d(silu(g)*u) of the feed-forward
  *      (modelling/llama.py:150); E = gate|up activations [M,2N], C = dg|du [M,2N], dh is not stored.
+ *      | 7 SwiGLU forward: B = [W_gate; W_up] (N = 2I, I % 128 == 0), C = gate|up [M,N] as usual, E = OUTPUT h [M,I] = silu(g)*u
+ *      (row stride lde); a tile covers 128 gate columns and the matching 128 up columns.
  *      K, K2 multiples of 64; N multiple of 8. ------------------------------------------------------------------- */
 int llx_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
                      const void* A2, int64_t lda2, const void* B2, int64_t ldb2, int64_t K2, int epilogue, const void* E, int64_t lde,

@@ -93,6 +93,17 @@ static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 // ---- SwiGLU pieces shared by the element-wise kernels and the GEMM epilogue (h = silu(g) * u, modelling/llama.py:150)
 // v_rcp_f32 (1 ulp) instead of the IEEE divide sequence: the result is rounded to bf16 right after
 __device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+// 8 packed bf16 elements: h = (silu(g) rounded) * u, rounded  -- the two roundings of the bf16 eager graph
+__device__ __forceinline__ u32x4_t swiglu_fwd8(const u32x4_t& gv, const u32x4_t& uv) {
+  u32x4_t o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float g0 = bflo(gv[e]), g1 = bfhi(gv[e]);
+    const float s0 = bf2f(f2bf(g0 * sigmoidf_(g0))), s1 = bf2f(f2bf(g1 * sigmoidf_(g1)));
+    o[e] = pack_bf2(s0 * bflo(uv[e]), s1 * bfhi(uv[e]));
+  }
+  return o;
+}
 // 8 packed bf16 elements: dg = (dh*u rounded) * silu'(g), du = dh * (silu(g) rounded)  -- the roundings autograd's bf16 graph makes
 __device__ __forceinline__ void swiglu_bwd8(const u32x4_t& dv, const u32x4_t& gv, const u32x4_t& uv, u32x4_t& og, u32x4_t& ou) {
 #pragma unroll

@@ -103,14 +103,7 @@ __global__ void swiglu_fwd_kernel(const bf16_t* __restrict__ g, const bf16_t* __
   const int c = (int)(idx % cpr) * 8;
   const u32x4_t gv = *reinterpret_cast<const u32x4_t*>(g + r * g_ld + c);
   const u32x4_t uv = *reinterpret_cast<const u32x4_t*>(u + r * u_ld + c);
-  u32x4_t o;
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const float g0 = bflo(gv[e]), g1 = bfhi(gv[e]);
-    const float s0 = bf2f(f2bf(g0 * sigmoidf_(g0))), s1 = bf2f(f2bf(g1 * sigmoidf_(g1)));
-    o[e] = pack_bf2(s0 * bflo(uv[e]), s1 * bfhi(uv[e]));
-  }
-  *reinterpret_cast<u32x4_t*>(h + r * h_ld + c) = o;
+  *reinterpret_cast<u32x4_t*>(h + r * h_ld + c) = swiglu_fwd8(gv, uv);
 }
 
 // dg = dh*u*silu'(g), du = dh*silu(g)

@@ -22,7 +22,7 @@
 #define EPI_ROW_BYTES 528                       // 512 B of bf16 + 16 B pad (bank spread for the ds_write_b64)
 #define GEMM_LDS_BYTES (256 * EPI_ROW_BYTES)    // 135168 >= 2 * STAGE_BYTES
 
-enum { EPI_NONE = 0, EPI_RESIDUAL = 1, EPI_BIAS = 2, EPI_BIAS_GELU = 3, EPI_COLSCALE = 4, EPI_ROWCOLSCALE = 5, EPI_SWIGLU_BWD = 6 };
+enum { EPI_NONE = 0, EPI_RESIDUAL = 1, EPI_BIAS = 2, EPI_BIAS_GELU = 3, EPI_COLSCALE = 4, EPI_ROWCOLSCALE = 5, EPI_SWIGLU_BWD = 6, EPI_SWIGLU_FWD = 7 };
 
 struct GemmArgs {
   const bf16_t* A; const bf16_t* B; bf16_t* C;
@@ -64,7 +64,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const GemmArgs g) {
   const int gsz = min(g.grid_m - group * GROUP_M, GROUP_M);
   const int pid_m = group * GROUP_M + ((bid % width) % gsz);
   const int pid_n = (bid % width) / gsz;
-  const int m0 = pid_m * BM, n0 = pid_n * BN;
+  // EPI_SWIGLU_FWD: B = [W_gate; W_up] (N = 2I rows).  A tile takes 128 gate columns AND the 128 up columns of the same hidden
+  // units (B rows n0.. and I + n0..), so the epilogue sees g and u of one h column side by side: grid_n = I / 128.
+  constexpr bool SPLITN = EPI == EPI_SWIGLU_FWD;
+  const int halfN = g.N >> 1;
+  const int m0 = pid_m * BM, n0 = SPLITN ? pid_n * (BN / 2) : pid_n * BN;
 
   // ---- staging addresses. LDS chunk q = i*512 + tid  -> row i*64 + (tid>>3), slot tid&7;
   // source chunk = slot ^ ((row>>1)&7) = (tid&7) ^ ((tid>>4)&7)   (independent of i).
@@ -74,7 +78,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const GemmArgs g) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     arow[i] = min(m0 + i * 64 + srow, g.M - 1);  // clamp: edge rows re-read a valid row, never stored
-    brow[i] = min(n0 + i * 64 + srow, g.N - 1);
+    brow[i] = SPLITN ? (i < 2 ? n0 + i * 64 + srow : halfN + n0 + (i - 2) * 64 + srow) : min(n0 + i * 64 + srow, g.N - 1);
   }
   const int nk1 = g.K / TK;
   const int nk = nk1 + g.K2 / TK;
@@ -286,6 +290,25 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const GemmArgs g) {
     }
   }
   __syncthreads();
+  if constexpr (SPLITN) {
+    // tile columns 0-127 = g, 128-255 = u of hidden units n0..n0+127: store both where the unfused layout has them, and
+    // h = silu(g) * u into E (used as an OUTPUT here, row stride lde)
+    bf16_t* H = const_cast<bf16_t*>(g.E);
+#pragma unroll 4
+    for (int it = 0; it < 8; ++it) {
+      const int q = it * 512 + tid;
+      const int row = q >> 4, cc = q & 15;
+      const int gm = m0 + row, gn = n0 + cc * 8;
+      if (gm < g.M) {
+        const u32x4_t gv = *reinterpret_cast<const u32x4_t*>(smem + row * EPI_ROW_BYTES + cc * 16);
+        const u32x4_t uv = *reinterpret_cast<const u32x4_t*>(smem + row * EPI_ROW_BYTES + (cc + 16) * 16);
+        *reinterpret_cast<u32x4_t*>(g.C + (int64_t)gm * g.ldc + gn) = gv;
+        *reinterpret_cast<u32x4_t*>(g.C + (int64_t)gm * g.ldc + halfN + gn) = uv;
+        *reinterpret_cast<u32x4_t*>(H + (int64_t)gm * g.lde + gn) = swiglu_fwd8(gv, uv);
+      }
+    }
+    return;
+  }
 #pragma unroll 4
   for (int it = 0; it < 16; ++it) {
     const int q = it * 512 + tid;
@@ -367,7 +390,8 @@ static int launch_gemm(const GemmArgs& a, hipStream_t stream) {
 // C[M,N] = A[M,K].B[N,K]^T (+ A2[M,K2].B2[N,K2]^T), bf16 in/out, fp32 accumulate.
 // ld* are row strides in elements.  K and K2 must be multiples of 64, N a multiple of 8, all pointers and row
 // strides 16-byte aligned.  epilogue: 0 none | 1 +E[M,N] (ld=lde) | 2 +bias E[N] | 3 gelu(+bias) | 4 *colscale E[N] |
-// 6 SwiGLU backward (E = gate|up [M,2N], C = dg|du [M,2N]).
+// 6 SwiGLU backward (E = gate|up [M,2N], C = dg|du [M,2N]) | 7 SwiGLU forward (B = [W_gate; W_up], C = gate|up [M,N],
+// E = OUTPUT h [M,N/2] = silu(g)*u, row stride lde).
 extern "C" int llx_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M,
                                 int64_t N, int64_t K, const void* A2, int64_t lda2, const void* B2, int64_t ldb2, int64_t K2,
                                 int epilogue, const void* E, int64_t lde, hipStream_t stream) {
@@ -397,6 +421,10 @@ extern "C" int llx_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64
     case EPI_BIAS_GELU: return launch_gemm<EPI_BIAS_GELU>(a, stream);
     case EPI_COLSCALE: return launch_gemm<EPI_COLSCALE>(a, stream);
     case EPI_SWIGLU_BWD: return launch_gemm<EPI_SWIGLU_BWD>(a, stream);
+    case EPI_SWIGLU_FWD:
+      LLX_REQUIRE(N % 256 == 0 && lde % 8 == 0, "llx_gemm_nt_bf16: the SwiGLU-forward epilogue needs N = 2I with I a multiple of 128");
+      a.grid_n = (int)(N / 256);
+      return launch_gemm<EPI_SWIGLU_FWD>(a, stream);
     default: llx_set_error("llx_gemm_nt_bf16: unknown epilogue %d", epilogue); return LLX_ERR_UNSUPPORTED;
   }
 }

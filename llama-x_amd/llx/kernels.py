@@ -17,6 +17,7 @@ from . import _lib as L
 BF16 = torch.bfloat16
 EPI_NONE, EPI_RESIDUAL, EPI_BIAS, EPI_BIAS_GELU, EPI_COLSCALE = 0, 1, 2, 3, 4
 EPI_SWIGLU_BWD = 6  # the product is dh; e = gate|up [M, 2N]; out = dg|du [M, 2N] (dh itself is not stored)
+EPI_SWIGLU_FWD = 7  # b = [W_gate; W_up]; out = gate|up [M, N]; e = OUTPUT h [M, N/2] = silu(g) * u
 SK_PAD = 64
 GEMM_TRACE = None  # bench.py sets this to a list to collect (start_event, end_event, algorithmic_flops) per GEMM launch
 
@@ -98,6 +99,9 @@ def gemm_nt(a: Tensor, b: Tensor, *, out: Optional[Tensor] = None, a2: Optional[
         assert e is not None and e.shape == (M, N) and e.stride(1) == 1
         lde = e.stride(0)
     elif epilogue == EPI_SWIGLU_BWD:
+        lde = e.stride(0)
+    elif epilogue == EPI_SWIGLU_FWD:
+        assert e is not None and N % 256 == 0 and e.shape == (M, N // 2) and e.stride(1) == 1
         lde = e.stride(0)
     elif epilogue != EPI_NONE:
         assert e is not None and e.shape == (N,) and e.is_contiguous()

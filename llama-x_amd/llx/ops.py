@@ -10,6 +10,8 @@ subclasses/int8.py:106-130.
 """
 from __future__ import annotations
 
+import os
+
 from typing import Optional, Sequence
 
 import torch
@@ -221,14 +223,14 @@ class GroupPlan:
         return _cached_multi(ss, "cat_scale", lambda: torch.cat(ss, 0) if len(ss) > 1 else ss[0])
 
     # ---- forward
-    def forward(self, x: Tensor, out: Optional[Tensor] = None, residual: Optional[Tensor] = None):
+    def forward(self, x: Tensor, out: Optional[Tensor] = None, residual: Optional[Tensor] = None, swiglu_h: Optional[Tensor] = None):
         """out: [M, sum N] (row-strided view allowed; allocated when None).  ``residual`` [M, sum N] is added in the GEMM
         epilogue (x + linear(..), modelling/llama.py:172-173).  Returns (out, saved) - saved feeds backward()."""
         if out is None:
             out = torch.empty(x.shape[0], self.N, device=x.device, dtype=BF16)
-        return out, self._forward(x, out, residual)
+        return out, self._forward(x, out, residual, swiglu_h)
 
-    def _forward(self, x: Tensor, out: Tensor, residual: Optional[Tensor]):
+    def _forward(self, x: Tensor, out: Tensor, residual: Optional[Tensor], swiglu_h: Optional[Tensor] = None):
         if not self.fused:
             assert residual is None or len(self.members) == 1
             return [m.forward(x, out=out[:, o : o + n], residual=residual)[1] for m, o, n in zip(self.members, self.n_off, self.Ns)]
@@ -241,6 +243,8 @@ class GroupPlan:
         if not self.int8:
             if residual is not None:
                 K.gemm_nt(x, self.w_cat(), out=out, a2=t[0] if t else None, b2=b2, epilogue=K.EPI_RESIDUAL, e=residual)
+            elif swiglu_h is not None:  # gate|up group: h = silu(g) * u leaves the same GEMM (g and u are stored as usual)
+                K.gemm_nt(x, self.w_cat(), out=out, a2=t[0] if t else None, b2=b2, epilogue=K.EPI_SWIGLU_FWD, e=swiglu_h)
             else:
                 K.gemm_nt(x, self.w_cat(), out=out, a2=t[0] if t else None, b2=b2)
             return t
@@ -508,6 +512,9 @@ class AttnBlockFn(Function):
 # =================================================================================================
 # MLP residual branch:  [x +] w2( silu(w1 xn) * w3 xn ),  xn = [rmsnorm(x)]
 # =================================================================================================
+_FUSE_SWIGLU_FWD = os.environ.get("LLX_FUSE_SWIGLU_FWD", "1") != "0"  # A/B knob: 0 = stand-alone swiglu_fwd kernel
+
+
 class MLPBlockMeta:
     def __init__(self, w13: GroupPlan, w2: GroupPlan, eps, fuse_norm, fuse_residual):
         self.w13, self.w2 = w13, w2
@@ -526,8 +533,12 @@ class MLPBlockFn(Function):
             xn, rstd = x2, None
         T, I = x2.shape[0], meta.w13.Ns[0]
         gu = torch.empty(T, 2 * I, device=x.device, dtype=BF16)
-        _, t13 = meta.w13.forward(xn, gu)
-        h = K.swiglu_fwd(gu[:, :I], gu[:, I:])
+        if meta.w13.fused and not meta.w13.int8 and len(meta.w13.members) == 2 and I % 128 == 0 and _FUSE_SWIGLU_FWD:
+            h = torch.empty(T, I, device=x.device, dtype=BF16)
+            _, t13 = meta.w13.forward(xn, gu, swiglu_h=h)  # SwiGLU in the epilogue of the gate|up GEMM
+        else:
+            _, t13 = meta.w13.forward(xn, gu)
+            h = K.swiglu_fwd(gu[:, :I], gu[:, I:])
         y, t2 = meta.w2.forward(h, None, x2 if meta.fuse_residual else None)
         ctx.meta = meta
         ctx.save_for_backward(x, norm_w)

@@ -85,6 +85,23 @@ def test_gemm_swiglu_bwd_epilogue(K, cuda, M, I, D, K2):
     assert torch.equal(out, ref)
 
 
+@pytest.mark.parametrize("M,I,D,K2", [(512, 768, 256, 64), (300, 1280, 128, 0), (4096, 1792, 512, 64)])
+def test_gemm_swiglu_fwd_epilogue(K, cuda, M, I, D, K2):
+    """gate|up GEMM with the SwiGLU in the epilogue (each tile = 128 gate + the matching 128 up columns): gate|up and h equal the
+    plain GEMM followed by the stand-alone swiglu_fwd, bit for bit."""
+    x = _bf(O.randn("x", (M, D))).to(cuda)
+    w = _bf(O.randn("w", (2 * I, D), 0.05)).to(cuda)
+    a2 = _bf(O.randn("a2", (M, K2))).to(cuda) if K2 else None
+    b2 = _bf(O.randn("b2", (2 * I, K2), 0.05)).to(cuda) if K2 else None
+    gu_ref = K.gemm_nt(x, w, a2=a2, b2=b2)
+    h_ref = K.swiglu_fwd(gu_ref[:, :I], gu_ref[:, I:])
+    gu = torch.empty_like(gu_ref)
+    h = torch.empty_like(h_ref)
+    K.gemm_nt(x, w, out=gu, a2=a2, b2=b2, epilogue=K.EPI_SWIGLU_FWD, e=h)
+    assert torch.equal(gu, gu_ref)
+    assert torch.equal(h, h_ref)
+
+
 def test_gemm_rejects_bad_shapes(K, cuda):
     from llx._lib import LlxError
 
