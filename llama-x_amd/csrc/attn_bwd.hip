@@ -187,14 +187,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnBwdArgs a
       f32x16_t st, dp;
       const f32x16_t zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       const int row = kb * 32 + r;
+      // S^T chain first, then the dP^T chain: the exponentials of S are VALU work that can issue under the second chain's MFMAs
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) {
         bf16x8_t kf = row_frag(sK, row, ks, hh);
         st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], ks == 0 ? zero : st, 0, 0, 0);
-        bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(sV + row * 256 + (((2 * ks + hh) ^ (row & 15)) << 4));
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[ks], ks == 0 ? zero : dp, 0, 0, 0);
       }
-      // dS^T = P^T * (dP^T - delta)
       if (cls != 2) {  // ONE wave-uniform branch per 32 keys: masked scores become -inf, exp2 turns them into 0
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
@@ -208,10 +206,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnBwdArgs a
         }
       }
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(st[e], a.scale_log2, -lse_safe));
-        st[e] = p * (dp[e] - my_delta);
+      for (int e = 0; e < 16; ++e) st[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[e], a.scale_log2, -lse_safe));
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(sV + row * 256 + (((2 * ks + hh) ^ (row & 15)) << 4));
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[ks], ks == 0 ? zero : dp, 0, 0, 0);
       }
+      // dS^T = P^T * (dP^T - delta)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) st[e] = st[e] * (dp[e] - my_delta);
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         bf16x8_t dsb;
