@@ -151,7 +151,7 @@ def main():
     # gradients (latency-bound on xGMI: ~1 ms) and the optimizer; --no-graph = eager launches with the exchange overlapped
     # with backward from autograd hooks.  N=1: the optimizer step is captured too.
     buckets = GradBuckets(model, n_buckets=4, force=force_dp, overlap=not use_graph)
-    optim = torch.optim.AdamW(trainable, lr=1e-4, weight_decay=0.0, fused=True, capturable=use_graph and not dp)
+    optim = torch.optim.AdamW(trainable, lr=1e-4, weight_decay=0.0, fused=True, capturable=use_graph)
 
     S = args.seq
     gen = torch.Generator(device=device)
@@ -208,6 +208,11 @@ def main():
                 static_loss.backward()
                 if not dp:
                     optim.step()
+            opt_graph = None
+            if dp:  # the optimizer step replays from its own graph after the gradient exchange
+                opt_graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(opt_graph):
+                    optim.step()
 
             def step():
                 ids, labels = batch()
@@ -216,10 +221,10 @@ def main():
                 graph.replay()
                 if dp:
                     buckets.finish()  # bucketed RCCL all-reduce of the flat gradient buffers
-                    optim.step()
+                    opt_graph.replay()
                 return static_loss
 
-            launch_mode = "hipGraph replay (fwd+bwd" + ("+AdamW)" if not dp else "), then RCCL all-reduce + AdamW")
+            launch_mode = "hipGraph replay (fwd+bwd" + ("+AdamW)" if not dp else "), RCCL all-reduce, hipGraph replay (AdamW)")
         except Exception as exc:  # noqa: BLE001 - a capture problem must not cost the measurement: fall back to eager launches
             print(f"[bench] graph capture failed ({type(exc).__name__}: {exc}); running eagerly", file=sys.stderr, flush=True)
             torch.cuda.synchronize()
