@@ -50,6 +50,12 @@ int llx_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* r
 int llx_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
                      const void* A2, int64_t lda2, const void* B2, int64_t ldb2, int64_t K2, int epilogue, const void* E, int64_t lde,
                      llx_stream_t s);
+/* The q|k|v projection with apply_rope (modelling/llama.py:118-125, 63-73) in the epilogue: columns [0, rope_cols) of C (whole
+ * 128-wide heads: q then k) are rotated with the fp32 table [>= rope_S, 64, 2]; row m of C is sequence position m % rope_S.
+ * Bit-identical to llx_gemm_nt_bf16(epilogue 0) followed by llx_rope. */
+int llx_gemm_nt_bf16_rope(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
+                          const void* A2, int64_t lda2, const void* B2, int64_t ldb2, int64_t K2, const float* rope_table, int64_t rope_S,
+                          int64_t rope_cols, llx_stream_t s);
 
 /* ---- torchao::int8_mm_dequant(A, B, A_scale, B_scale) - subclasses/int8_mm.py:121-149 (Triton kernel :50-118).
  *      A int8 [M,K]; B passed as its K-contiguous rows [N,K] (= the reference's int_data.T view, strides (1,K));
@@ -79,7 +85,8 @@ int64_t llx_attn_bwd_workspace_bytes(int64_t B, int64_t S, int64_t H, int64_t KV
 int llx_attn_bwd(const void* q, int64_t q_sb, int64_t q_ss, const void* k, int64_t k_sb, int64_t k_ss, const void* v, int64_t v_sb,
                  int64_t v_ss, const void* o, int64_t o_sb, int64_t o_ss, const void* d_o, int64_t do_sb, int64_t do_ss, const float* lse,
                  float* delta /* fp32 workspace, llx_attn_bwd_workspace_bytes() */, void* dq, int64_t dq_sb, int64_t dq_ss, void* dk, int64_t dk_sb, int64_t dk_ss,
-                 void* dv, int64_t dv_sb, int64_t dv_ss, const int* doc_ids, const int* prefix_len, const void* flags, int64_t B,
+                 void* dv, int64_t dv_sb, int64_t dv_ss, const int* doc_ids, const int* prefix_len, const void* flags,
+                 const float* rope /* nullable fp32 [>=S,64,2]: dq, dk leave already multiplied by apply_rope's transpose */, int64_t B,
                  int64_t S, int64_t H, int64_t KVH, int64_t head_dim, float scale, llx_stream_t s);
 
 /* ---- dense-mask attention forward (inference / KV-cache path): SDPA(q,k,v,mask,is_causal=False,enable_gqa=True) at

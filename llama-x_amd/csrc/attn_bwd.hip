@@ -49,6 +49,7 @@ __device__ __forceinline__ bf16x8_t row_frag(const char* img, int row, int ks, i
 struct AttnBwdArgs {
   const bf16_t* q; const bf16_t* k; const bf16_t* v; const bf16_t* o; const bf16_t* d_o;
   const float* lse; float* delta; float* nlse;
+  const float* rope;  // nullable: fp32 table [>= S, 64, 2]; dq and dk leave the kernels already rotated by -theta (apply_rope's transpose)
   unsigned long long* stamps;  // diagnostic (normally null): s_memtime stamps of workgroup 0, wave 0 of the dK/dV kernel
   bf16_t* dq; bf16_t* dk; bf16_t* dv;
   int64_t q_sb, q_ss, k_sb, k_ss, v_sb, v_ss, o_sb, o_ss, do_sb, do_ss;
@@ -242,6 +243,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnBwdArgs a
         u32x2_t pk;
         pk[0] = pack_bf2(dq[db][4 * g4 + 0] * a.scale, dq[db][4 * g4 + 1] * a.scale);
         pk[1] = pack_bf2(dq[db][4 * g4 + 2] * a.scale, dq[db][4 * g4 + 3] * a.scale);
+        if (a.rope) {  // gradient of apply_rope on the bf16-rounded dq, exactly as the stand-alone rope kernel computes it
+          const f32x4_t t = *reinterpret_cast<const f32x4_t*>(a.rope + ((int64_t)qi * 64 + ((32 * db + 8 * g4 + 4 * hh) >> 1)) * 2);
+          const float c0 = t[0], s0 = t[1] * -1.f, c1 = t[2], s1 = t[3] * -1.f;
+          const float x0 = bflo(pk[0]), x1 = bfhi(pk[0]), y0 = bflo(pk[1]), y1 = bfhi(pk[1]);
+          pk[0] = pack_bf2(x0 * c0 - x1 * s0, x1 * c0 + x0 * s0);
+          pk[1] = pack_bf2(y0 * c1 - y1 * s1, y1 * c1 + y0 * s1);
+        }
         *reinterpret_cast<u32x2_t*>(op + 32 * db + 8 * g4 + 4 * hh) = pk;
       }
   }
@@ -749,6 +757,7 @@ __global__ void attn_dkv_reduce_kernel(const AttnBwdArgs a, const float* __restr
     ok[e] = pack_bf2(sk[2 * e] * a.scale, sk[2 * e + 1] * a.scale);
     ov[e] = pack_bf2(sv[2 * e], sv[2 * e + 1]);
   }
+  if (a.rope) ok = rope8(ok, a.rope + ((int64_t)key * 64 + (d >> 1)) * 2, -1.f);
   *reinterpret_cast<u32x4_t*>(a.dk + b * a.dk_sb + (int64_t)key * a.dk_ss + kvh * HD + d) = ok;
   *reinterpret_cast<u32x4_t*>(a.dv + b * a.dv_sb + (int64_t)key * a.dv_ss + kvh * HD + d) = ov;
 }
@@ -766,12 +775,14 @@ extern "C" int64_t llx_attn_bwd_workspace_bytes(int64_t B, int64_t S, int64_t H,
 }
 
 // delta: fp32 workspace of llx_attn_bwd_workspace_bytes() bytes.  All strides in elements.  flags as in llx_attn_fwd.
+// rope (nullable): fp32 table [>= S, 64, 2]; when given, q and k are the ROTATED projections and dq, dk come out as the
+// gradients of the un-rotated ones (apply_rope's transpose fused into the dQ epilogue and the dK/dV reduce).
 extern "C" int llx_attn_bwd(const void* q, int64_t q_sb, int64_t q_ss, const void* k, int64_t k_sb, int64_t k_ss, const void* v,
                             int64_t v_sb, int64_t v_ss, const void* o, int64_t o_sb, int64_t o_ss, const void* d_o, int64_t do_sb,
                             int64_t do_ss, const float* lse, float* delta, void* dq, int64_t dq_sb, int64_t dq_ss, void* dk,
                             int64_t dk_sb, int64_t dk_ss, void* dv, int64_t dv_sb, int64_t dv_ss, const int* doc_ids,
-                            const int* prefix_len, const void* flags, int64_t B, int64_t S, int64_t H, int64_t KVH, int64_t head_dim,
-                            float scale, hipStream_t stream) {
+                            const int* prefix_len, const void* flags, const float* rope, int64_t B, int64_t S, int64_t H, int64_t KVH,
+                            int64_t head_dim, float scale, hipStream_t stream) {
   LLX_REQUIRE(q && k && v && o && d_o && lse && delta && dq && dk && dv, "llx_attn_bwd: null pointer");
   LLX_REQUIRE(head_dim == HD, "llx_attn_bwd: head_dim=%lld unsupported (only 128)", (long long)head_dim);
   LLX_REQUIRE(B > 0 && S > 0 && H > 0 && KVH > 0 && H % KVH == 0, "llx_attn_bwd: bad B/S/H/KVH");
@@ -781,6 +792,7 @@ extern "C" int llx_attn_bwd(const void* q, int64_t q_sb, int64_t q_ss, const voi
   LLX_REQUIRE(((uintptr_t)dq) % 8 == 0 && ((uintptr_t)dk | (uintptr_t)dv) % 16 == 0 && ((dk_ss | dv_ss | dk_sb | dv_sb) % 8) == 0,
               "llx_attn_bwd: unaligned output");
   LLX_REQUIRE(!(doc_ids || prefix_len) || flags, "llx_attn_bwd: tile flags required with doc_ids/prefix_len");
+  LLX_REQUIRE(!rope || (uintptr_t)rope % 16 == 0, "llx_attn_bwd: unaligned rope table");
   if (!g_bwd_attr) {
     hipError_t e1 = hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, DQ_LDS_BYTES);
     hipError_t e4 = hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, DQ_LDS_BYTES);
@@ -793,7 +805,7 @@ extern "C" int llx_attn_bwd(const void* q, int64_t q_sb, int64_t q_ss, const voi
   }
   AttnBwdArgs a;
   a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.o = (const bf16_t*)o; a.d_o = (const bf16_t*)d_o;
-  a.lse = lse; a.delta = delta; a.nlse = delta + B * H * S; a.stamps = nullptr; a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk; a.dv = (bf16_t*)dv;
+  a.lse = lse; a.delta = delta; a.nlse = delta + B * H * S; a.stamps = nullptr; a.rope = rope; a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk; a.dv = (bf16_t*)dv;
   a.q_sb = q_sb; a.q_ss = q_ss; a.k_sb = k_sb; a.k_ss = k_ss; a.v_sb = v_sb; a.v_ss = v_ss; a.o_sb = o_sb; a.o_ss = o_ss;
   a.do_sb = do_sb; a.do_ss = do_ss; a.dq_sb = dq_sb; a.dq_ss = dq_ss; a.dk_sb = dk_sb; a.dk_ss = dk_ss; a.dv_sb = dv_sb; a.dv_ss = dv_ss;
   a.doc_ids = doc_ids; a.prefix_len = prefix_len; a.flags = (doc_ids || prefix_len) ? (const uint8_t*)flags : nullptr;

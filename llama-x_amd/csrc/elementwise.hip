@@ -65,16 +65,7 @@ __global__ void rope_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y
   const int64_t b = bs / S;
   const u32x4_t v = *reinterpret_cast<const u32x4_t*>(x + b * x_sb + (int64_t)s * x_ss + h * 128 + sub * 8);
   const float* tp = table + ((int64_t)s * 64 + sub * 4) * 2;
-  const f32x4_t t0 = *reinterpret_cast<const f32x4_t*>(tp);
-  const f32x4_t t1 = *reinterpret_cast<const f32x4_t*>(tp + 4);
-  const float cs[4] = {t0[0], t0[2], t1[0], t1[2]};
-  const float sn[4] = {t0[1] * sign, t0[3] * sign, t1[1] * sign, t1[3] * sign};
-  u32x4_t o;
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const float x0 = bflo(v[e]), x1 = bfhi(v[e]);
-    o[e] = pack_bf2(x0 * cs[e] - x1 * sn[e], x1 * cs[e] + x0 * sn[e]);
-  }
+  const u32x4_t o = rope8(v, tp, sign);
   *reinterpret_cast<u32x4_t*>(y + b * y_sb + (int64_t)s * y_ss + h * 128 + sub * 8) = o;
 }
 

@@ -22,7 +22,7 @@
 #define EPI_ROW_BYTES 528                       // 512 B of bf16 + 16 B pad (bank spread for the ds_write_b64)
 #define GEMM_LDS_BYTES (256 * EPI_ROW_BYTES)    // 135168 >= 2 * STAGE_BYTES
 
-enum { EPI_NONE = 0, EPI_RESIDUAL = 1, EPI_BIAS = 2, EPI_BIAS_GELU = 3, EPI_COLSCALE = 4, EPI_ROWCOLSCALE = 5, EPI_SWIGLU_BWD = 6, EPI_SWIGLU_FWD = 7 };
+enum { EPI_NONE = 0, EPI_RESIDUAL = 1, EPI_BIAS = 2, EPI_BIAS_GELU = 3, EPI_COLSCALE = 4, EPI_ROWCOLSCALE = 5, EPI_SWIGLU_BWD = 6, EPI_SWIGLU_FWD = 7, EPI_ROPE = 8 };
 
 struct GemmArgs {
   const bf16_t* A; const bf16_t* B; bf16_t* C;
@@ -32,6 +32,8 @@ struct GemmArgs {
   int64_t lda, ldb, ldc, lde, lda2, ldb2;
   int M, N, K, K2;
   int grid_m, grid_n;
+  const float* rope;       // EPI_ROPE: fp32 table [>= rope_S, 64, 2]; row m sits at position m % rope_S
+  int rope_S, rope_cols;   //           columns [0, rope_cols) (whole 128-wide heads) are rotated
 };
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -341,6 +343,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const GemmArgs g) {
         swiglu_bwd8(v, gv, uv, og, ou);
         *reinterpret_cast<u32x4_t*>(g.C + (int64_t)gm * g.ldc + g.N + gn) = ou;
         v = og;
+      } else if constexpr (EPI == EPI_ROPE) {
+        // q|k|v projection: apply_rope on the q and k heads right here (modelling/llama.py:118-125); v holds the bf16-rounded
+        // projection exactly as the stand-alone GEMM would have stored it, the rotation is the one of rope_kernel
+        if (gn < g.rope_cols) v = rope8(v, g.rope + ((int64_t)(gm % g.rope_S) * 64 + ((gn & 127) >> 1)) * 2, 1.f);
       } else if constexpr (EPI == EPI_COLSCALE) {
         // weight-only int8: (x @ W_i8^T) rounded to bf16, then * scale[n] (subclasses/int8.py:118)
         u32x4_t s = *reinterpret_cast<const u32x4_t*>(g.E + gn);
@@ -392,9 +398,10 @@ static int launch_gemm(const GemmArgs& a, hipStream_t stream) {
 // strides 16-byte aligned.  epilogue: 0 none | 1 +E[M,N] (ld=lde) | 2 +bias E[N] | 3 gelu(+bias) | 4 *colscale E[N] |
 // 6 SwiGLU backward (E = gate|up [M,2N], C = dg|du [M,2N]) | 7 SwiGLU forward (B = [W_gate; W_up], C = gate|up [M,N],
 // E = OUTPUT h [M,N/2] = silu(g)*u, row stride lde).
-extern "C" int llx_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M,
-                                int64_t N, int64_t K, const void* A2, int64_t lda2, const void* B2, int64_t ldb2, int64_t K2,
-                                int epilogue, const void* E, int64_t lde, hipStream_t stream) {
+static int gemm_nt_bf16_impl(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M,
+                             int64_t N, int64_t K, const void* A2, int64_t lda2, const void* B2, int64_t ldb2, int64_t K2,
+                             int epilogue, const void* E, int64_t lde, const float* rope, int64_t rope_S, int64_t rope_cols,
+                             hipStream_t stream) {
   LLX_REQUIRE(A && B && C, "llx_gemm_nt_bf16: null pointer");
   LLX_REQUIRE(M > 0 && N > 0 && K > 0, "llx_gemm_nt_bf16: empty problem M=%lld N=%lld K=%lld", (long long)M, (long long)N, (long long)K);
   LLX_REQUIRE(K % BK == 0 && K2 % BK == 0, "llx_gemm_nt_bf16: K=%lld and K2=%lld must be multiples of 64", (long long)K, (long long)K2);
@@ -403,7 +410,9 @@ extern "C" int llx_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64
   LLX_REQUIRE(((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) % 16 == 0, "llx_gemm_nt_bf16: pointers must be 16-byte aligned");
   LLX_REQUIRE(K2 == 0 || (A2 && B2 && lda2 % 8 == 0 && ldb2 % 8 == 0 && ((uintptr_t)A2 | (uintptr_t)B2) % 16 == 0),
               "llx_gemm_nt_bf16: bad K-extension operands");
-  LLX_REQUIRE(epilogue == EPI_NONE || (E && (uintptr_t)E % 16 == 0), "llx_gemm_nt_bf16: epilogue operand missing/unaligned");
+  LLX_REQUIRE(epilogue == EPI_NONE || epilogue == EPI_ROPE || (E && (uintptr_t)E % 16 == 0), "llx_gemm_nt_bf16: epilogue operand missing/unaligned");
+  LLX_REQUIRE(epilogue != EPI_ROPE || (rope && (uintptr_t)rope % 16 == 0 && rope_S > 0 && rope_cols >= 0 && rope_cols <= N && rope_cols % 128 == 0),
+              "llx_gemm_nt_bf16_rope: need an aligned fp32 table, rope_S > 0 and rope_cols a multiple of 128 within N");
   LLX_REQUIRE((epilogue != EPI_RESIDUAL && epilogue != EPI_SWIGLU_BWD) || lde % 8 == 0, "llx_gemm_nt_bf16: residual / gate|up stride must be a multiple of 8");
   LLX_REQUIRE(epilogue != EPI_SWIGLU_BWD || (lde >= 2 * N && ldc >= 2 * N), "llx_gemm_nt_bf16: the SwiGLU-backward epilogue reads E[M,2N] (gate|up) and writes C[M,2N] (dg|du)");
   LLX_REQUIRE(M < (1 << 30) && N < (1 << 30) && K < (1 << 30), "llx_gemm_nt_bf16: dimension too large");
@@ -414,6 +423,7 @@ extern "C" int llx_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64
   a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.lde = lde; a.lda2 = lda2; a.ldb2 = ldb2;
   a.M = (int)M; a.N = (int)N; a.K = (int)K; a.K2 = (int)K2;
   a.grid_m = (int)cdiv64(M, BM); a.grid_n = (int)cdiv64(N, BN);
+  a.rope = rope; a.rope_S = (int)rope_S; a.rope_cols = (int)rope_cols;
   switch (epilogue) {
     case EPI_NONE: return launch_gemm<EPI_NONE>(a, stream);
     case EPI_RESIDUAL: return launch_gemm<EPI_RESIDUAL>(a, stream);
@@ -421,12 +431,29 @@ extern "C" int llx_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64
     case EPI_BIAS_GELU: return launch_gemm<EPI_BIAS_GELU>(a, stream);
     case EPI_COLSCALE: return launch_gemm<EPI_COLSCALE>(a, stream);
     case EPI_SWIGLU_BWD: return launch_gemm<EPI_SWIGLU_BWD>(a, stream);
+    case EPI_ROPE: return launch_gemm<EPI_ROPE>(a, stream);
     case EPI_SWIGLU_FWD:
       LLX_REQUIRE(N % 256 == 0 && lde % 8 == 0, "llx_gemm_nt_bf16: the SwiGLU-forward epilogue needs N = 2I with I a multiple of 128");
       a.grid_n = (int)(N / 256);
       return launch_gemm<EPI_SWIGLU_FWD>(a, stream);
     default: llx_set_error("llx_gemm_nt_bf16: unknown epilogue %d", epilogue); return LLX_ERR_UNSUPPORTED;
   }
+}
+
+extern "C" int llx_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M,
+                                int64_t N, int64_t K, const void* A2, int64_t lda2, const void* B2, int64_t ldb2, int64_t K2,
+                                int epilogue, const void* E, int64_t lde, hipStream_t stream) {
+  LLX_REQUIRE(epilogue != EPI_ROPE, "llx_gemm_nt_bf16: the RoPE epilogue is llx_gemm_nt_bf16_rope");
+  return gemm_nt_bf16_impl(A, lda, B, ldb, C, ldc, M, N, K, A2, lda2, B2, ldb2, K2, epilogue, E, lde, nullptr, 0, 0, stream);
+}
+
+// The q|k|v projection with apply_rope in the epilogue (modelling/llama.py:118-125): as llx_gemm_nt_bf16 with epilogue 0, then
+// columns [0, rope_cols) of C (the q and k heads, 128 wide each) are rotated with the fp32 table [>= rope_S, 64, 2]; row m of C is
+// sequence position m % rope_S.  Bit-identical to the plain GEMM followed by llx_rope.
+extern "C" int llx_gemm_nt_bf16_rope(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M, int64_t N,
+                                     int64_t K, const void* A2, int64_t lda2, const void* B2, int64_t ldb2, int64_t K2,
+                                     const float* rope_table, int64_t rope_S, int64_t rope_cols, hipStream_t stream) {
+  return gemm_nt_bf16_impl(A, lda, B, ldb, C, ldc, M, N, K, A2, lda2, B2, ldb2, K2, EPI_ROPE, nullptr, 0, rope_table, rope_S, rope_cols, stream);
 }
 
 // torchao::int8_mm_dequant (subclasses/int8_mm.py:121-149): C[M,N] = (A_i8[M,K] . B_i8[N,K]^T)_int32 * a_scale[m] * b_scale[n]
@@ -446,5 +473,6 @@ extern "C" int llx_int8_mm_dequant(const void* A, int64_t lda, const void* B, in
   a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.lde = 0; a.lda2 = 0; a.ldb2 = 0;
   a.M = (int)M; a.N = (int)N; a.K = (int)K; a.K2 = 0;
   a.grid_m = (int)cdiv64(M, BM); a.grid_n = (int)cdiv64(N, BN);
+  a.rope = nullptr; a.rope_S = 0; a.rope_cols = 0;
   return launch_gemm<EPI_ROWCOLSCALE, true>(a, stream);
 }

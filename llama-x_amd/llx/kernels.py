@@ -76,8 +76,9 @@ def rmsnorm_bwd(dy: Tensor, x: Tensor, w: Tensor, rstd: Tensor, need_dw: bool, d
 
 # ------------------------------------------------------------------------------------------------- gemm
 def gemm_nt(a: Tensor, b: Tensor, *, out: Optional[Tensor] = None, a2: Optional[Tensor] = None, b2: Optional[Tensor] = None,
-            epilogue: int = EPI_NONE, e: Optional[Tensor] = None) -> Tensor:
-    """out[M,N] = a[M,K] @ b[N,K]^T (+ a2[M,K2] @ b2[N,K2]^T) with a fused epilogue; bf16, fp32 accumulate."""
+            epilogue: int = EPI_NONE, e: Optional[Tensor] = None, rope: Optional[tuple[Tensor, int, int]] = None) -> Tensor:
+    """out[M,N] = a[M,K] @ b[N,K]^T (+ a2[M,K2] @ b2[N,K2]^T) with a fused epilogue; bf16, fp32 accumulate.
+    rope = (fp32 table [>= S, 64, 2], S, cols): apply_rope on columns [0, cols) of out in the epilogue (row m = position m % S)."""
     _chk_bf16(a, b, a2, b2, e, out)
     assert a.dim() == 2 and b.dim() == 2 and a.shape[1] == b.shape[1], (a.shape, b.shape)
     assert a.stride(1) == 1 and b.stride(1) == 1
@@ -109,9 +110,16 @@ def gemm_nt(a: Tensor, b: Tensor, *, out: Optional[Tensor] = None, a2: Optional[
     if GEMM_TRACE is not None:
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         ev[0].record()
-    L.check(_lib().llx_gemm_nt_bf16(L.ptr(a), a.stride(0), L.ptr(b), b.stride(0), L.ptr(out), out.stride(0), M, N, K,
-                                    L.ptr(a2), a2.stride(0) if a2 is not None else 0, L.ptr(b2), b2.stride(0) if b2 is not None else 0, K2,
-                                    epilogue, L.ptr(e), lde, L.stream()), "llx_gemm_nt_bf16")
+    if rope is not None:
+        table, rs, rc = rope
+        assert epilogue == EPI_NONE and table.dtype is torch.float32 and table.is_contiguous() and table.shape[0] >= rs and table.shape[1:] == (64, 2)
+        L.check(_lib().llx_gemm_nt_bf16_rope(L.ptr(a), a.stride(0), L.ptr(b), b.stride(0), L.ptr(out), out.stride(0), M, N, K,
+                                             L.ptr(a2), a2.stride(0) if a2 is not None else 0, L.ptr(b2), b2.stride(0) if b2 is not None else 0, K2,
+                                             L.ptr(table), rs, rc, L.stream()), "llx_gemm_nt_bf16_rope")
+    else:
+        L.check(_lib().llx_gemm_nt_bf16(L.ptr(a), a.stride(0), L.ptr(b), b.stride(0), L.ptr(out), out.stride(0), M, N, K,
+                                        L.ptr(a2), a2.stride(0) if a2 is not None else 0, L.ptr(b2), b2.stride(0) if b2 is not None else 0, K2,
+                                        epilogue, L.ptr(e), lde, L.stream()), "llx_gemm_nt_bf16")
     if ev is not None:
         ev[1].record()
         GEMM_TRACE.append((ev[0], ev[1], 2.0 * M * N * (K + K2), 2.0 * (M * (K + K2) + N * (K + K2) + M * N * (2 if epilogue == EPI_RESIDUAL else 1))))
@@ -362,8 +370,11 @@ def attn_fwd(q: Tensor, k: Tensor, v: Tensor, mask: Optional[MaskSpec] = None) -
 
 
 def attn_bwd(q: Tensor, k: Tensor, v: Tensor, o: Tensor, do: Tensor, lse: Tensor, dq: Tensor, dk: Tensor, dv: Tensor,
-             mask: Optional[MaskSpec] = None) -> None:
+             mask: Optional[MaskSpec] = None, rope: Optional[Tensor] = None) -> None:
+    """rope (fp32 table [>= S, 64, 2]): q, k are the rotated projections; dq, dk come out as gradients of the un-rotated ones."""
     _chk_bf16(q, k, v, o, do, dq, dk, dv)
+    if rope is not None:
+        assert rope.dtype is torch.float32 and rope.is_contiguous() and rope.shape[0] >= q.shape[1] and rope.shape[1:] == (64, 2)
     B, S, H, hd = q.shape
     KVH = k.shape[2]
     for t in (q, k, v, o, do, dq, dk, dv):
@@ -376,7 +387,8 @@ def attn_bwd(q: Tensor, k: Tensor, v: Tensor, o: Tensor, do: Tensor, lse: Tensor
     L.check(_lib().llx_attn_bwd(L.ptr(q), q.stride(0), q.stride(1), L.ptr(k), k.stride(0), k.stride(1), L.ptr(v), v.stride(0), v.stride(1),
                                 L.ptr(o), o.stride(0), o.stride(1), L.ptr(do), do.stride(0), do.stride(1), L.ptr(lse), L.ptr(delta),
                                 L.ptr(dq), dq.stride(0), dq.stride(1), L.ptr(dk), dk.stride(0), dk.stride(1), L.ptr(dv), dv.stride(0),
-                                dv.stride(1), L.ptr(d), L.ptr(p), L.ptr(fl), B, S, H, KVH, hd, 1.0 / math.sqrt(hd), L.stream()), "llx_attn_bwd")
+                                dv.stride(1), L.ptr(d), L.ptr(p), L.ptr(fl), L.ptr(rope), B, S, H, KVH, hd, 1.0 / math.sqrt(hd), L.stream()),
+            "llx_attn_bwd")
 
 
 def attn_dense_fwd(q: Tensor, k: Tensor, v: Tensor, mask: Tensor) -> Tensor:

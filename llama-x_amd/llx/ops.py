@@ -223,14 +223,20 @@ class GroupPlan:
         return _cached_multi(ss, "cat_scale", lambda: torch.cat(ss, 0) if len(ss) > 1 else ss[0])
 
     # ---- forward
-    def forward(self, x: Tensor, out: Optional[Tensor] = None, residual: Optional[Tensor] = None, swiglu_h: Optional[Tensor] = None):
+    def forward(self, x: Tensor, out: Optional[Tensor] = None, residual: Optional[Tensor] = None, swiglu_h: Optional[Tensor] = None,
+                rope: Optional[tuple[Tensor, int, int]] = None):
         """out: [M, sum N] (row-strided view allowed; allocated when None).  ``residual`` [M, sum N] is added in the GEMM
         epilogue (x + linear(..), modelling/llama.py:172-173).  Returns (out, saved) - saved feeds backward()."""
         if out is None:
             out = torch.empty(x.shape[0], self.N, device=x.device, dtype=BF16)
-        return out, self._forward(x, out, residual, swiglu_h)
+        return out, self._forward(x, out, residual, swiglu_h, rope)
 
-    def _forward(self, x: Tensor, out: Tensor, residual: Optional[Tensor], swiglu_h: Optional[Tensor] = None):
+    def rope_fusable(self) -> bool:
+        """apply_rope can ride in the projection GEMM's epilogue (one fused bf16 GEMM writes the whole q|k|v row)."""
+        return self.fused and not self.int8
+
+    def _forward(self, x: Tensor, out: Tensor, residual: Optional[Tensor], swiglu_h: Optional[Tensor] = None,
+                 rope: Optional[tuple[Tensor, int, int]] = None):
         if not self.fused:
             assert residual is None or len(self.members) == 1
             return [m.forward(x, out=out[:, o : o + n], residual=residual)[1] for m, o, n in zip(self.members, self.n_off, self.Ns)]
@@ -246,7 +252,7 @@ class GroupPlan:
             elif swiglu_h is not None:  # gate|up group: h = silu(g) * u leaves the same GEMM (g and u are stored as usual)
                 K.gemm_nt(x, self.w_cat(), out=out, a2=t[0] if t else None, b2=b2, epilogue=K.EPI_SWIGLU_FWD, e=swiglu_h)
             else:
-                K.gemm_nt(x, self.w_cat(), out=out, a2=t[0] if t else None, b2=b2)
+                K.gemm_nt(x, self.w_cat(), out=out, a2=t[0] if t else None, b2=b2, rope=rope)
             return t
         if self.dynamic:
             from subclasses.int8 import quantize_int8_rowwise
@@ -455,9 +461,11 @@ class AttnBlockFn(Function):
             xn, rstd = x2, None
         W = (H + 2 * KVH) * hd
         qkv = torch.empty(B * S, W, device=x.device, dtype=BF16)
-        _, tqkv = meta.qkv.forward(xn, qkv)
+        fuse_rope = meta.qkv.rope_fusable() and _FUSE_ROPE
+        _, tqkv = meta.qkv.forward(xn, qkv, rope=(rope, S, (H + KVH) * hd) if fuse_rope else None)
         qkv3 = qkv.view(B, S, W)
-        K.rope_(qkv3, rope, H + KVH)
+        if not fuse_rope:
+            K.rope_(qkv3, rope, H + KVH)
         q = qkv3[..., : H * hd].unflatten(-1, (H, hd))
         k = qkv3[..., H * hd : (H + KVH) * hd].unflatten(-1, (KVH, hd))
         v = qkv3[..., (H + KVH) * hd :].unflatten(-1, (KVH, hd))
@@ -491,8 +499,11 @@ class AttnBlockFn(Function):
         dq = dqkv[..., : H * hd].unflatten(-1, (H, hd))
         dk = dqkv[..., H * hd : (H + KVH) * hd].unflatten(-1, (KVH, hd))
         dv = dqkv[..., (H + KVH) * hd :].unflatten(-1, (KVH, hd))
-        K.attn_bwd(q, k, v, o, do2.view(B, S, H, hd), lse, dq, dk, dv, meta.mask)
-        K.rope_(dqkv, rope, H + KVH, backward=True)
+        if _FUSE_ROPE:  # apply_rope's transpose rides in the dQ epilogue and the dK/dV reduce
+            K.attn_bwd(q, k, v, o, do2.view(B, S, H, hd), lse, dq, dk, dv, meta.mask, rope=rope)
+        else:
+            K.attn_bwd(q, k, v, o, do2.view(B, S, H, hd), lse, dq, dk, dv, meta.mask)
+            K.rope_(dqkv, rope, H + KVH, backward=True)
         d2 = dqkv.view(B * S, W)
         need_dx = ctx.needs_input_grad[0]
         need_dxn = need_dx or (meta.fuse_norm and ctx.needs_input_grad[2])  # the norm weight gradient needs d(xn) too
@@ -513,6 +524,7 @@ class AttnBlockFn(Function):
 # MLP residual branch:  [x +] w2( silu(w1 xn) * w3 xn ),  xn = [rmsnorm(x)]
 # =================================================================================================
 _FUSE_SWIGLU_FWD = os.environ.get("LLX_FUSE_SWIGLU_FWD", "1") != "0"  # A/B knob: 0 = stand-alone swiglu_fwd kernel
+_FUSE_ROPE = os.environ.get("LLX_FUSE_ROPE", "1") != "0"  # A/B knob: 0 = stand-alone rope kernel after the projection / before its dgrad
 
 
 class MLPBlockMeta:

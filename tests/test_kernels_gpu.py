@@ -102,6 +102,39 @@ def test_gemm_swiglu_fwd_epilogue(K, cuda, M, I, D, K2):
     assert torch.equal(h, h_ref)
 
 
+def test_gemm_rope_epilogue_and_attn_bwd_rope(K, cuda):
+    """apply_rope fused into the q|k|v projection GEMM, and its transpose fused into the attention backward, equal the
+    stand-alone rope kernel applied after / before, bit for bit."""
+    B, S, H, KVH, D = 2, 384, 4, 1, 256
+    W = (H + 2 * KVH) * 128
+    table = O.rope_table(O.TINY)[:S].contiguous().to(cuda)
+    x = _bf(O.randn("x", (B * S, D))).to(cuda)
+    w = _bf(O.randn("w", (W, D), 0.05)).to(cuda)
+    a2 = _bf(O.randn("a2", (B * S, 64))).to(cuda)
+    b2 = _bf(O.randn("b2", (W, 64), 0.05)).to(cuda)
+    ref = K.gemm_nt(x, w, a2=a2, b2=b2)
+    K.rope_(ref.view(B, S, W), table, H + KVH)
+    out = torch.empty_like(ref)
+    K.gemm_nt(x, w, out=out, a2=a2, b2=b2, rope=(table, S, (H + KVH) * 128))
+    assert torch.equal(out, ref)
+    # backward
+    qkv = out.view(B, S, W)
+    q = qkv[..., : H * 128].unflatten(-1, (H, 128)); k = qkv[..., H * 128 : (H + KVH) * 128].unflatten(-1, (KVH, 128)); v = qkv[..., (H + KVH) * 128 :].unflatten(-1, (KVH, 128))
+    o, lse = K.attn_fwd(q, k, v)
+    do = _bf(O.randn("do", (B, S, H, 128))).to(cuda)
+    res = []
+    for fused in (False, True):
+        dqkv = torch.zeros(B, S, W, device=cuda, dtype=torch.bfloat16)
+        dq = dqkv[..., : H * 128].unflatten(-1, (H, 128)); dk = dqkv[..., H * 128 : (H + KVH) * 128].unflatten(-1, (KVH, 128)); dv = dqkv[..., (H + KVH) * 128 :].unflatten(-1, (KVH, 128))
+        if fused:
+            K.attn_bwd(q, k, v, o, do, lse, dq, dk, dv, rope=table)
+        else:
+            K.attn_bwd(q, k, v, o, do, lse, dq, dk, dv)
+            K.rope_(dqkv, table, H + KVH, backward=True)
+        res.append(dqkv)
+    assert torch.equal(res[0], res[1])
+
+
 def test_gemm_rejects_bad_shapes(K, cuda):
     from llx._lib import LlxError
 
