@@ -3,10 +3,9 @@
 // Gradients of softmax(QK^T*scale + mask)V as autograd produces them for the reference's SDPA / FlexAttention
 // call (modelling/llama.py:129-137).  P is recomputed from Q, K and the forward's log2-sum-exp.  Deterministic:
 // no atomics.  Three launches:
-//   1. attn_delta_kernel : delta[b,h,q] = sum_d dO.O
-//   2. attn_bwd_dq_kernel: one workgroup = 128 query rows of one head, sweeps key tiles      -> dQ
-//   3. attn_bwd_dkv2_kernel: one workgroup = 128 keys x ONE query head, sweeps 64-row query tiles -> fp32 partial dK, dV
-//      attn_dkv_reduce_kernel: sums the G per-head partials of a KV group                    -> dK, dV
+//   1. attn_bwd_dq_kernel: one workgroup = 128 query rows of one head, sweeps key tiles      -> dQ, and delta[b,h,q] = sum_d dO.O
+//   2. attn_bwd_dkv3_kernel: one workgroup = 128 keys x ONE query head, sweeps 64-row query tiles -> fp32 partial dK, dV
+//   3. attn_dkv_reduce_kernel: sums the G per-head partials of a KV group                    -> dK, dV
 // MFMA orientation keeps the softmax row index where the row constants (lse, delta) are cheap:
 //   dq kernel : S^T = K.Q^T, dP^T = V.dO^T (query on the lane), dQ^T += K^T.dS^T with dS^T taken from the accumulator
 //               registers as the B operand and K^T read from the SAME LDS image by ds_read_b64_tr_b16.
@@ -59,34 +58,6 @@ struct AttnBwdArgs {
   float scale, scale_log2;
 };
 
-// ------------------------------------------------------------------------------------------ delta
-__global__ void attn_delta_kernel(const AttnBwdArgs a) {
-  // 16 lanes per (q, h) row of 128 elements; 16 rows per 256-thread block
-  const int64_t row = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
-  const int sub = threadIdx.x & 15;
-  const int64_t total = (int64_t)a.B * a.S * a.H;
-  float acc = 0.f;
-  if (row < total) {
-    const int h = (int)(row % a.H);
-    const int64_t bs = row / a.H;
-    const int s = (int)(bs % a.S), b = (int)(bs / a.S);
-    u32x4_t x = *reinterpret_cast<const u32x4_t*>(a.o + b * a.o_sb + s * a.o_ss + h * HD + sub * 8);
-    u32x4_t y = *reinterpret_cast<const u32x4_t*>(a.d_o + b * a.do_sb + s * a.do_ss + h * HD + sub * 8);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) acc += bflo(x[e]) * bflo(y[e]) + bfhi(x[e]) * bfhi(y[e]);
-  }
-#pragma unroll
-  for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-  if (row < total && sub == 0) {
-    const int h = (int)(row % a.H);
-    const int64_t bs = row / a.H;
-    const int s = (int)(bs % a.S), b = (int)(bs / a.S);
-    a.delta[((int64_t)b * a.H + h) * a.S + s] = acc;
-    const float l = a.lse[((int64_t)b * a.H + h) * a.S + s];
-    a.nlse[((int64_t)b * a.H + h) * a.S + s] = (l == -INFINITY) ? 0.f : -l;  // what the dK/dV kernel adds inside exp2
-  }
-}
-
 // ------------------------------------------------------------------------------------------ dQ
 #define DQ_STAGE_BYTES (2 * TILE_BYTES)
 #define DQ_LDS_BYTES (2 * DQ_STAGE_BYTES)
@@ -115,8 +86,25 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnBwdArgs a
     }
   }
   const float my_lse = a.lse[((int64_t)b * a.H + h) * a.S + qrow];
-  const float my_delta = a.delta[((int64_t)b * a.H + h) * a.S + qrow];
   const float lse_safe = (my_lse == -INFINITY) ? 0.f : my_lse;
+  // delta = rowsum(dO . O): this kernel holds its rows' dO fragments already, so it computes delta itself (half a row per
+  // lane, the partner half-wave holds the other half) and publishes delta and the sanitised -lse for the dK/dV kernel,
+  // which runs after it.  (Replaces a separate pass over O and dO.)
+  float my_delta = 0.f;
+  {
+    const bf16_t* op = a.o + (int64_t)b * a.o_sb + (int64_t)qrow * a.o_ss + h * HD + 8 * hh;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const bf16x8_t ov = *reinterpret_cast<const bf16x8_t*>(op + 16 * ks);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) my_delta += (float)ov[j] * (float)dof[ks][j];
+    }
+    my_delta += __shfl_xor(my_delta, 32, 64);
+    if (hh == 0 && qi < a.S) {
+      a.delta[((int64_t)b * a.H + h) * a.S + qi] = my_delta;
+      a.nlse[((int64_t)b * a.H + h) * a.S + qi] = -lse_safe;
+    }
+  }
 
   const uint8_t* fl = GENERAL ? a.flags + ((int64_t)b * nqb + qb) * nkt : nullptr;
   const int kt_end = GENERAL ? nkt : min(nkt, (qb * BQ + BQ + BKV - 1) / BKV);
@@ -655,7 +643,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv3_kernel(const AttnBwdArgs
         }
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
-          // stats hold -lse with -inf rows sanitised to 0 (written by attn_delta_kernel)
+          // stats hold -lse with -inf rows sanitised to 0 (written by attn_bwd_dq_kernel)
           const f32x4_t l4 = *(lds_f32x4*)((lds_char*)(uintptr_t)Ls + (qb32 * 32 + 8 * g4) * 4);
 #pragma unroll
           for (int e2 = 0; e2 < 4; ++e2) st[4 * g4 + e2] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[4 * g4 + e2], a.scale_log2, l4[e2]));
@@ -811,9 +799,10 @@ extern "C" int llx_attn_bwd(const void* q, int64_t q_sb, int64_t q_ss, const voi
   a.doc_ids = doc_ids; a.prefix_len = prefix_len; a.flags = (doc_ids || prefix_len) ? (const uint8_t*)flags : nullptr;
   a.B = (int)B; a.S = (int)S; a.H = (int)H; a.KVH = (int)KVH;
   a.scale = scale; a.scale_log2 = scale * 1.4426950408889634f;
-  const int64_t rows = B * S * H;
-  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)cdiv64(rows, 16)), dim3(256), 0, stream, a);
-  LLX_LAUNCH_CHECK("llx_attn_bwd(delta)");
+  // dQ first: it also publishes delta = rowsum(dO . O) and the sanitised -lse that the dK/dV kernel stages from global memory
+  if (a.flags) hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, dim3((unsigned)H, (unsigned)cdiv64(S, BQ), (unsigned)B), dim3(256), DQ_LDS_BYTES, stream, a);
+  else hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, dim3((unsigned)H, (unsigned)cdiv64(S, BQ), (unsigned)B), dim3(256), DQ_LDS_BYTES, stream, a);
+  LLX_LAUNCH_CHECK("llx_attn_bwd(dq)");
   {
     float* part = delta + 2 * B * H * S;
     const int64_t nkb = cdiv64(S, DKV2_KEYS);
@@ -834,8 +823,5 @@ extern "C" int llx_attn_bwd(const void* q, int64_t q_sb, int64_t q_ss, const voi
     hipLaunchKernelGGL(attn_dkv_reduce_kernel, dim3((unsigned)cdiv64(plane / 8, 256)), dim3(256), 0, stream, a, (const float*)part);
     LLX_LAUNCH_CHECK("llx_attn_bwd(dkv reduce)");
   }
-  if (a.flags) hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, dim3((unsigned)H, (unsigned)cdiv64(S, BQ), (unsigned)B), dim3(256), DQ_LDS_BYTES, stream, a);
-  else hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, dim3((unsigned)H, (unsigned)cdiv64(S, BQ), (unsigned)B), dim3(256), DQ_LDS_BYTES, stream, a);
-  LLX_LAUNCH_CHECK("llx_attn_bwd(dq)");
   return LLX_OK;
 }
