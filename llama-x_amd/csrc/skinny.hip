@@ -3,6 +3,7 @@
 //   skinny_tn :  G[R, N]     = s * U[M, R]^T . Y[M, N]       (d lora_a = s * u^T x ; d lora_b^T = s * t^T dy)
 // Both are HBM-bound on the big operand (X or Y, read once); R <= 64 rides on 16x16x32 MFMA tiles.
 #include "common.h"
+#include <cstdlib>
 
 typedef __attribute__((address_space(3))) s16x4_t lds_s16x4;
 typedef __attribute__((ext_vector_type(8))) short s16x8_t;
@@ -163,19 +164,21 @@ __global__ __launch_bounds__(256) void skinny_tn_kernel(const bf16_t* __restrict
 #pragma unroll
     for (int cb = 0; cb < 4; ++cb) acc[rb][cb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  for (int ms = m_begin; ms < m_end; ms += TN_MS) {
-    // global -> registers (zero rows past the end / columns past N)
-    u32x4_t yv[4], uv;
+  // global -> registers (zero rows past the end / columns past N); the loads of step i+1 are issued right after step i's
+  // registers have been written to LDS, so they fly under step i's transposed reads and MFMAs
+  u32x4_t yv[4], uv;
+  auto load_step = [&](int ms) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int q = i * 256 + tid;  // chunk of 16 B: row q>>5, chunk q&31
       const int row = ms + (q >> 5), col = n0 + (q & 31) * 8;
       yv[i] = (row < m_end && col < N) ? *reinterpret_cast<const u32x4_t*>(Y + (int64_t)row * ldy + col) : u32x4_t{0u, 0u, 0u, 0u};
     }
-    {
-      const int row = ms + (tid >> 3);
-      uv = (row < m_end) ? *reinterpret_cast<const u32x4_t*>(U + (int64_t)row * SK_PAD + (tid & 7) * 8) : u32x4_t{0u, 0u, 0u, 0u};
-    }
+    const int row = ms + (tid >> 3);
+    uv = (row < m_end) ? *reinterpret_cast<const u32x4_t*>(U + (int64_t)row * SK_PAD + (tid & 7) * 8) : u32x4_t{0u, 0u, 0u, 0u};
+  };
+  if (m_begin < m_end) load_step(m_begin);
+  for (int ms = m_begin; ms < m_end; ms += TN_MS) {
     __syncthreads();  // previous step's reads are done
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -184,6 +187,7 @@ __global__ __launch_bounds__(256) void skinny_tn_kernel(const bf16_t* __restrict
     }
     *reinterpret_cast<u32x4_t*>(sU + (tid >> 3) * TN_UROW + (tid & 7) * 16) = uv;
     __syncthreads();
+    if (ms + TN_MS < m_end) load_step(ms + TN_MS);
     bf16x8_t a[NB];
 #pragma unroll
     for (int rb = 0; rb < NB; ++rb) a[rb] = tr16_frag(sU, TN_UROW, rb * 16, lane);
@@ -246,7 +250,8 @@ __global__ void skinny_tn_reduce_segs_kernel(const float* __restrict__ partial, 
 
 static int tn_splits(int64_t M, int64_t N) {
   const int64_t ntiles = cdiv64(N, TN_NT);
-  int64_t want = cdiv64(512, ntiles);           // ~2 blocks per CU
+  static const int target = getenv("LLX_TN_BLOCKS") ? atoi(getenv("LLX_TN_BLOCKS")) : 384;
+  int64_t want = cdiv64(target, ntiles);        // blocks per launch: 384 measured best over 128..1024 on the step's shapes (fewer, longer blocks and a smaller reduce)
   const int64_t max_split = cdiv64(M, 4 * TN_MS);  // at least 4 steps per block
   if (want > max_split) want = max_split;
   if (want < 1) want = 1;
