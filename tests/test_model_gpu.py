@@ -346,14 +346,15 @@ def test_kv_cache_prefill_and_decode(cuda):
         layer(hid.to(cuda).requires_grad_(), model.rope[:384], mask=dense.to(cuda))
 
 
-def test_full_dimension_layer_parity(cuda):
-    """One TransformerLayer at the REAL Llama-3.1-8B dimensions (D 4096, 32/8 heads, I 14336, LoRA r=16, S=512) against the
-    oracle: exercises the production tile shapes (N = 6144 / 28672 fused groups, K-extension, GQA 4:1, 256-key causal tiles)."""
+@pytest.mark.parametrize("S", [512, 2048])
+def test_full_dimension_layer_parity(cuda, S):
+    """One TransformerLayer at the REAL Llama-3.1-8B dimensions (D 4096, 32/8 heads, I 14336, LoRA r=16) against the oracle:
+    exercises the production tile shapes (N = 6144 / 28672 fused groups with RoPE / SwiGLU epilogues, K-extension, block-diagonal
+    LoRA operands, GQA 4:1, multi-tile causal attention; S = 2048 adds multi-round GEMM grids and 16-tile key sweeps)."""
     from modelling import apply_linear_adapter_
     from modelling.llama import LlamaConfig, TransformerLayer, build_rope
 
-    cfg = O.LLAMA31_8B._replace(num_layers=1, max_seq_len=512)
-    S = 512
+    cfg = O.LLAMA31_8B._replace(num_layers=1, max_seq_len=S)
     p = {k: v for k, v in O.init_params(cfg._replace(vocab_size=8)).items() if k.startswith("layers.0.")}
     p.update(O.init_lora(cfg, 16))
     pb, pf = bf16_params(p)
