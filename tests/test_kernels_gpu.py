@@ -40,6 +40,26 @@ def test_rmsnorm_fwd_bwd(K, cuda, rows, dim):
     torch.testing.assert_close(dw.cpu().float(), wr.grad, atol=1e-2 * wr.grad.abs().max().item(), rtol=2e-2)
 
 
+@pytest.mark.parametrize("rows,dim,need_dw", [(33, 1024, True), (300, 4096, True), (1000, 4096, False), (64, 8192, True), (5, 2048, True)])
+def test_rmsnorm_bwd_residual_join(K, cuda, rows, dim, need_dw):
+    """dx + dres in the same pass (the gradient arriving around the residual connection): equals bf16(dx) + dres as the separate
+    add would produce it, for ragged row counts, both register-pipeline variants (dim <= 4096 / 8192) and with or without dw."""
+    x = _bf(O.randn("x", (rows, dim))).to(cuda)
+    w = _bf(1 + O.randn("w", (dim,), 0.1)).to(cuda)
+    dy = _bf(O.randn("dy", (rows, dim))).to(cuda)
+    dres = _bf(O.randn("dres", (rows, dim))).to(cuda)
+    _, rstd = K.rmsnorm_fwd(x, w, 1e-5)
+    dx0, dw0 = K.rmsnorm_bwd(dy, x, w, rstd, need_dw)
+    dx1, dw1 = K.rmsnorm_bwd(dy, x, w, rstd, need_dw, dres)
+    assert torch.equal(dx1, (dx0.float() + dres.float()).bfloat16())
+    if need_dw:
+        assert torch.equal(dw0, dw1)
+        xr, wr = x.float().cpu().requires_grad_(), w.float().cpu().requires_grad_()
+        O.rmsnorm(xr, wr).backward(dy.float().cpu())
+        torch.testing.assert_close(dw1.cpu().float(), wr.grad, atol=1e-2 * wr.grad.abs().max().item(), rtol=2e-2)
+        torch.testing.assert_close(dx0.cpu().float(), xr.grad, atol=2e-2, rtol=2e-2)
+
+
 @pytest.mark.parametrize("M,N,K_,K2,epi", [(256, 256, 64, 0, 0), (384, 1792, 512, 0, 0), (100, 520, 192, 64, 0), (512, 512, 1792, 64, 1),
                                             (300, 264, 384, 0, 3), (1000, 1024, 512, 0, 2), (4096, 1024, 4096, 0, 4)])
 def test_gemm_nt(K, cuda, M, N, K_, K2, epi):
