@@ -201,7 +201,7 @@ def main():
             torch.cuda.current_stream().wait_stream(side)
             buckets.zero_grad()
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):  # the RCCL watchdog thread may poll events meanwhile
                 if dp:
                     buckets.zero_grad()  # captured memset of the flat buckets (param.grad are views into them)
                 static_loss = run_model(ids_buf, labels_buf)
@@ -211,7 +211,7 @@ def main():
             opt_graph = None
             if dp:  # the optimizer step replays from its own graph after the gradient exchange
                 opt_graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(opt_graph):
+                with torch.cuda.graph(opt_graph, capture_error_mode="thread_local"):
                     optim.step()
 
             def step():
