@@ -187,7 +187,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnFwdArgs a) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) mx = fmaxf(mx, st[kb][e]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * a.scale_log2;  // scale > 0: max commutes with the scaling
-    const float m_new = fmaxf(m_run, mx);
+    // Deferred running maximum: the base of the exponentials only moves when some row's maximum grew by more than 2^8 (one
+    // wave-uniform decision per tile).  Until then p = exp2(s - m_stale) <= 256 - bf16 keeps its relative precision there and
+    // O / l are normalised by the same base at the end - and the 64-register rescale of O is skipped on almost every tile.
+    const float m_cand = fmaxf(m_run, mx);
+    const bool move_base = __builtin_amdgcn_ballot_w64(m_cand > m_run + 8.f) != 0;
+    const float m_new = move_base ? m_cand : m_run;
     const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
     float rs = 0.f;
 #pragma unroll
@@ -199,7 +204,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnFwdArgs a) {
         rs += p;
       }
     rs += __shfl_xor(rs, 32, 64);
-    if (__builtin_amdgcn_ballot_w64(m_new != m_run) != 0) {  // some row's maximum moved: rescale (wave-uniform branch)
+    if (move_base) {  // rescale every row to its current maximum (rows that did not move get alpha = 1)
       const float alpha = __builtin_amdgcn_exp2f(m_run - m_safe);  // m_run = -inf -> 0
       l_run *= alpha;
 #pragma unroll
