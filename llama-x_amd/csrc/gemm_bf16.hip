@@ -83,7 +83,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const GemmArgs g) {
     brow[i] = SPLITN ? (i < 2 ? n0 + i * 64 + srow : halfN + n0 + (i - 2) * 64 + srow) : min(n0 + i * 64 + srow, g.N - 1);
   }
   const int nk1 = g.K / TK;
-  const int nk = nk1 + g.K2 / TK;
+  const int nk = nk1 + g.K2 / 64;  // K-extension tiles are bf16: 64 elements per 128-byte row
 
   // Per-lane source offsets are loop invariant (row * stride + swizzled chunk, 32-bit bytes); per K-tile only the
   // wave-uniform base pointer advances, so the loads need no vector address arithmetic inside the loop.
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const GemmArgs g) {
         __builtin_amdgcn_global_load_lds((gbl_void*)(base + (half ? boff[i] : aoff[i])), (lds_void*)(sT + (i * 512 + wave * 64) * 16), 16, 0, 0);
     } else {  // K-extension tiles (LoRA operands): a different pointer / stride pair, at most a few tiles per launch
       const char* base = (const char*)(half ? g.B2 : g.A2) + (int64_t)(kt - nk1) * 128;
-      const int64_t l = (half ? g.ldb2 : g.lda2) * ESZ;
+      const int64_t l = (half ? g.ldb2 : g.lda2) * 2;  // the K-extension operands are bf16 in the int8 kernel too
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const char* src = base + (int64_t)(half ? brow[i] : arow[i]) * l + schunk * 16;
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const GemmArgs g) {
           __builtin_amdgcn_global_load_lds((gbl_void*)(base + (half ? boff[2 * hi + j] : aoff[2 * hi + j])), (lds_void*)(sT + (j * 512 + wave * 64) * 16), 16, 0, 0);
       } else {
         const char* base = (const char*)(half ? g.B2 : g.A2) + (int64_t)(kt - nk1) * 128;
-        const int64_t l = (half ? g.ldb2 : g.lda2) * ESZ;
+        const int64_t l = (half ? g.ldb2 : g.lda2) * 2;  // the K-extension operands are bf16 in the int8 kernel too
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           const char* src = base + (int64_t)(half ? brow[2 * hi + j] : arow[2 * hi + j]) * l + schunk * 16;
@@ -190,14 +190,44 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const GemmArgs g) {
         }
       }
     };
-    auto mfma = [&](const i32x4_t& b, const i32x4_t& a, acc_t& c) {
-      if constexpr (I8) c = __builtin_amdgcn_mfma_i32_16x16x64_i8(b, a, c, 0, 0, 0);
-      else c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, b), __builtin_bit_cast(bf16x8_t, a), c, 0, 0, 0);
+    // int8 kernel with a K-extension (LoRA on an int8 base, dynamic activations): after the last int8 K-tile the int32
+    // accumulators are dequantised IN PLACE (acc * a_scale[m] * b_scale[n], rounded to bf16 as the reference's int8_mm_dequant
+    // output is, kept as fp32 bits) and the bf16 extension tiles accumulate on top with the bf16 MFMA.
+    auto mfma_t = [&](auto ext_tag, const i32x4_t& b, const i32x4_t& a, acc_t& c) {
+      constexpr bool ext_phase = decltype(ext_tag)::value;
+      if constexpr (I8) {
+        if constexpr (ext_phase) {
+          f32x4_t cf = __builtin_bit_cast(f32x4_t, c);
+          cf = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, b), __builtin_bit_cast(bf16x8_t, a), cf, 0, 0, 0);
+          c = __builtin_bit_cast(acc_t, cf);
+        } else {
+          c = __builtin_amdgcn_mfma_i32_16x16x64_i8(b, a, c, 0, 0, 0);
+        }
+      } else {
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, b), __builtin_bit_cast(bf16x8_t, a), c, 0, 0, 0);
+      }
+    };
+    auto dequant_in_place = [&]() {
+      if constexpr (I8) {
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) {
+          const float rs = bf2f(g.E2[min(m0 + wm * 128 + mi * 16 + frow, g.M - 1)]);
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni) {
+            const int n = wn * 64 + ni * 16 + fq * 4;
+            f32x4_t cf;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) cf[e] = bf2f(f2bf(((float)acc[mi][ni][e] * rs) * bf2f(g.E[min(n0 + n + e, g.N - 1)])));
+            acc[mi][ni] = __builtin_bit_cast(acc_t, cf);
+          }
+        }
+      }
     };
     // prologue: all of tile 0, then B-lo, B-hi, A-lo of tile 1
     stage_q(0, 0); stage_q(0, 1); stage_q(0, 2); stage_q(0, 3);
     stage_q(1, 2); stage_q(1, 3); stage_q(1, 0);
-    for (int kt = 0; kt < nk; ++kt) {
+    auto ktile = [&](int kt, auto ext_tag) __attribute__((always_inline)) {
+      auto mfma = [&](const i32x4_t& b, const i32x4_t& a, acc_t& c) { mfma_t(ext_tag, b, a, c); };
       const char* sA = smem + (kt & 1) * STAGE_BYTES;
       const char* sB = sA + A_TILE_BYTES;
       // ---------------- phase 0: tile kt has landed once all but the 6 youngest loads (3 half-tiles of kt+1) are done
@@ -263,6 +293,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const GemmArgs g) {
 #pragma unroll
           for (int n2 = 0; n2 < 2; ++n2) mfma(bfr[ks][n2], af[ks * 4 + m4], acc[4 + m4][n2]);
       __builtin_amdgcn_s_setprio(0);
+    };
+    const int nk_main = I8 ? nk1 : nk;  // bf16: the K-extension tiles use the same MFMA and simply continue the loop
+    for (int kt = 0; kt < nk_main; ++kt) ktile(kt, std::false_type{});
+    if constexpr (I8) {
+      if (nk > nk1) {
+        dequant_in_place();
+        for (int kt = nk1; kt < nk; ++kt) ktile(kt, std::true_type{});
+      }
     }
     __syncthreads();  // all LDS reads done before the epilogue reuses the stages
   }
@@ -278,9 +316,15 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const GemmArgs g) {
       const int n = wn * 64 + ni * 16 + fq * 4;
       float c[4];
       if constexpr (I8) {
-        // acc.to(fp32) * a_scale * b_scale, one rounding to the scale dtype (subclasses/int8_mm.py:112-118)
+        if (g.K2 > 0) {  // dequantised in place before the K-extension: the registers hold fp32 bits
+          const f32x4_t cf = __builtin_bit_cast(f32x4_t, acc[mi][ni]);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) c[e] = ((float)acc[mi][ni][e] * rs) * bf2f(g.E[min(n0 + n + e, g.N - 1)]);
+          for (int e = 0; e < 4; ++e) c[e] = cf[e];
+        } else {
+          // acc.to(fp32) * a_scale * b_scale, one rounding to the scale dtype (subclasses/int8_mm.py:112-118)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) c[e] = ((float)acc[mi][ni][e] * rs) * bf2f(g.E[min(n0 + n + e, g.N - 1)]);
+        }
       } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e) c[e] = acc[mi][ni][e];
@@ -472,6 +516,30 @@ extern "C" int llx_int8_mm_dequant(const void* A, int64_t lda, const void* B, in
   a.E = (const bf16_t*)b_scale; a.E2 = (const bf16_t*)a_scale;
   a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.lde = 0; a.lda2 = 0; a.ldb2 = 0;
   a.M = (int)M; a.N = (int)N; a.K = (int)K; a.K2 = 0;
+  a.grid_m = (int)cdiv64(M, BM); a.grid_n = (int)cdiv64(N, BN);
+  a.rope = nullptr; a.rope_S = 0; a.rope_cols = 0;
+  return launch_gemm<EPI_ROWCOLSCALE, true>(a, stream);
+}
+
+// torchao::int8_mm_dequant followed by a LoRA term in the same launch (an int8 base with dynamically quantised activations and a
+// bf16 adapter, subclasses/int8.py:110-118 + modelling/lora.py:43): C = bf16( bf16(int8_mm_dequant(A, B, a_scale, b_scale)) +
+// A2[M,K2].B2[N,K2]^T ) with A2/B2 bf16 and K2 a multiple of 64; the int32 accumulators are dequantised in place and the
+// extension accumulates on top in fp32.
+extern "C" int llx_int8_mm_dequant_ext(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M, int64_t N,
+                                       int64_t K, const void* a_scale, const void* b_scale, const void* A2, int64_t lda2, const void* B2,
+                                       int64_t ldb2, int64_t K2, hipStream_t stream) {
+  LLX_REQUIRE(A && B && C && a_scale && b_scale && A2 && B2, "llx_int8_mm_dequant_ext: null pointer");
+  LLX_REQUIRE(M > 0 && N > 0 && K > 0 && K2 > 0, "llx_int8_mm_dequant_ext: empty problem");
+  LLX_REQUIRE(K % 128 == 0 && K2 % 64 == 0, "llx_int8_mm_dequant_ext: K=%lld must be a multiple of 128 and K2=%lld of 64", (long long)K, (long long)K2);
+  LLX_REQUIRE(N % 8 == 0 && ldc % 8 == 0, "llx_int8_mm_dequant_ext: N and ldc must be multiples of 8");
+  LLX_REQUIRE(lda % 16 == 0 && ldb % 16 == 0 && lda2 % 8 == 0 && ldb2 % 8 == 0, "llx_int8_mm_dequant_ext: row strides (int8: multiples of 16, bf16: of 8)");
+  LLX_REQUIRE(((uintptr_t)A | (uintptr_t)B | (uintptr_t)C | (uintptr_t)A2 | (uintptr_t)B2) % 16 == 0, "llx_int8_mm_dequant_ext: pointers must be 16-byte aligned");
+  LLX_REQUIRE(gemm_pipe_mode() == 1, "llx_int8_mm_dequant_ext: needs the four-phase main loop (LLX_GEMM_PIPE unset or 1)");
+  GemmArgs a;
+  a.A = (const bf16_t*)A; a.B = (const bf16_t*)B; a.C = (bf16_t*)C; a.A2 = (const bf16_t*)A2; a.B2 = (const bf16_t*)B2;
+  a.E = (const bf16_t*)b_scale; a.E2 = (const bf16_t*)a_scale;
+  a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.lde = 0; a.lda2 = lda2; a.ldb2 = ldb2;
+  a.M = (int)M; a.N = (int)N; a.K = (int)K; a.K2 = (int)K2;
   a.grid_m = (int)cdiv64(M, BM); a.grid_n = (int)cdiv64(N, BN);
   a.rope = nullptr; a.rope_S = 0; a.rope_cols = 0;
   return launch_gemm<EPI_ROWCOLSCALE, true>(a, stream);

@@ -259,7 +259,12 @@ class GroupPlan:
             from subclasses.int8_mm import _launch as i8_gemm
 
             xi, xs = quantize_int8_rowwise(x)
-            direct = self.R == 0 and residual is None
+            if self.R > 0:  # the adapter rides in the int8 GEMM: int32 accumulators dequantised in place, then the bf16 K-extension
+                y0 = i8_gemm(xi, self.w_cat(), xs, self.scale_cat(), out=out if residual is None else None, a2=t[0], b2=b2)
+                if residual is not None:
+                    K.add(y0, residual, out=out)
+                return t
+            direct = residual is None
             y0 = i8_gemm(xi, self.w_cat(), xs, self.scale_cat(), out=out if direct else None)
         else:
             direct = self.R == 0 and residual is None

@@ -155,6 +155,30 @@ def test_gemm_rope_epilogue_and_attn_bwd_rope(K, cuda):
     assert torch.equal(res[0], res[1])
 
 
+@pytest.mark.parametrize("M,N,Kd,K2", [(300, 520, 256, 64), (1024, 1792, 512, 64), (4096, 6144, 1024, 128)])
+def test_int8_mm_dequant_with_lora_extension(K, cuda, M, N, Kd, K2):
+    """llx_int8_mm_dequant_ext = bf16(int8_mm_dequant) + a2 @ b2^T with the adapter accumulated on top of the dequantised
+    accumulators in fp32: equals the two-launch path (int8 GEMM, then bf16 GEMM with residual epilogue) to bf16 rounding, and the
+    plain entry point is untouched (bit-exact integer product)."""
+    from subclasses.int8_mm import _launch
+
+    a = O.randint("a", (M, Kd), -127, 128).to(torch.int8).to(cuda)
+    b = O.randint("b", (N, Kd), -127, 128).to(torch.int8).to(cuda)
+    sa = _bf(O.uniform("sa", (M,), 0.001, 0.01)).to(cuda)
+    sb = _bf(O.uniform("sb", (N,), 0.001, 0.01)).to(cuda)
+    a2 = _bf(O.randn("a2", (M, K2))).to(cuda)
+    b2 = _bf(O.randn("b2", (N, K2), 0.05)).to(cuda)
+    base = _launch(a, b, sa, sb)
+    exact = ((a.cpu().int() @ b.cpu().int().T).float() * sa.cpu().float()[:, None] * sb.cpu().float()[None, :]).bfloat16()
+    assert torch.equal(base.cpu(), exact)
+    two = K.gemm_nt(a2, b2, epilogue=K.EPI_RESIDUAL, e=base)
+    one = _launch(a, b, sa, sb, a2=a2, b2=b2)
+    ref = exact.float() + a2.cpu().float() @ b2.cpu().float().T
+    tol = 2 ** -7 * ref.abs().max().item()
+    torch.testing.assert_close(one.cpu().float(), ref, atol=tol, rtol=2 ** -7)
+    torch.testing.assert_close(one.float(), two.float(), atol=tol, rtol=2 ** -6)
+
+
 def test_gemm_rejects_bad_shapes(K, cuda):
     from llx._lib import LlxError
 
