@@ -62,11 +62,13 @@ int llx_gemm_nt_bf16_rope(const void* A, int64_t lda, const void* B, int64_t ldb
  *      scales bf16; C bf16 = (int32 acc) * a_scale[m] * b_scale[n], one rounding.  K multiple of 128. ----------- */
 int llx_int8_mm_dequant(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
                         const void* a_scale, const void* b_scale, llx_stream_t s);
-/* The same followed by a LoRA term in the same launch (int8 base, dynamically quantised activations, bf16 adapter -
- * subclasses/int8.py:110-118 + modelling/lora.py:43): C = bf16( bf16(int8_mm_dequant(...)) + A2[M,K2].B2[N,K2]^T ), A2/B2 bf16,
- * K2 a multiple of 64.  The int32 accumulators are dequantised in place and the extension accumulates on top in fp32. */
+/* The same with the neighbours of its call sites fused in (int8 base, dynamically quantised activations - subclasses/int8.py:110-118):
+ * C = epilogue( bf16( bf16(int8_mm_dequant(A, B, a_scale, b_scale)) + A2[M,K2].B2[N,K2]^T ) ).  A2/B2 (nullable; bf16, K2 % 64 == 0):
+ * the LoRA adapter (modelling/lora.py:43) - the int32 accumulators are dequantised in place, the extension accumulates on top in fp32.
+ * epilogue: 0 none | 1 + E[M,N] (ld = lde) | 7 SwiGLU forward (E = OUTPUT h) | 8 RoPE on columns [0, rope_cols), as llx_gemm_nt_bf16(_rope). */
 int llx_int8_mm_dequant_ext(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
                             const void* a_scale, const void* b_scale, const void* A2, int64_t lda2, const void* B2, int64_t ldb2, int64_t K2,
+                            int epilogue, const void* E, int64_t lde, const float* rope_table, int64_t rope_S, int64_t rope_cols,
                             llx_stream_t s);
 
 /* ---- quantize_int8_rowwise - subclasses/int8.py:10-16 (weights once, activations per forward when dynamic). ---- */

@@ -32,6 +32,7 @@ struct GemmArgs {
   int64_t lda, ldb, ldc, lde, lda2, ldb2;
   int M, N, K, K2;
   int grid_m, grid_n;
+  const bf16_t* sa; const bf16_t* sb;  // int8 kernel: A_scale_rowwise[M], B_scale_colwise[N] (E / lde stay free for the epilogue)
   const float* rope;       // EPI_ROPE: fp32 table [>= rope_S, 64, 2]; row m sits at position m % rope_S
   int rope_S, rope_cols;   //           columns [0, rope_cols) (whole 128-wide heads) are rotated
 };
@@ -71,6 +72,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const GemmArgs g) {
   constexpr bool SPLITN = EPI == EPI_SWIGLU_FWD;
   const int halfN = g.N >> 1;
   const int m0 = pid_m * BM, n0 = SPLITN ? pid_n * (BN / 2) : pid_n * BN;
+  // output column (= B row) of tile-local column nl
+  auto col_of = [&](int nl) { return SPLITN ? (nl < BN / 2 ? n0 + nl : halfN + n0 + nl - BN / 2) : min(n0 + nl, g.N - 1); };
 
   // ---- staging addresses. LDS chunk q = i*512 + tid  -> row i*64 + (tid>>3), slot tid&7;
   // source chunk = slot ^ ((row>>1)&7) = (tid&7) ^ ((tid>>4)&7)   (independent of i).
@@ -211,13 +214,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const GemmArgs g) {
       if constexpr (I8) {
 #pragma unroll
         for (int mi = 0; mi < 8; ++mi) {
-          const float rs = bf2f(g.E2[min(m0 + wm * 128 + mi * 16 + frow, g.M - 1)]);
+          const float rs = bf2f(g.sa[min(m0 + wm * 128 + mi * 16 + frow, g.M - 1)]);
 #pragma unroll
           for (int ni = 0; ni < 4; ++ni) {
             const int n = wn * 64 + ni * 16 + fq * 4;
             f32x4_t cf;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) cf[e] = bf2f(f2bf(((float)acc[mi][ni][e] * rs) * bf2f(g.E[min(n0 + n + e, g.N - 1)])));
+            for (int e = 0; e < 4; ++e) cf[e] = bf2f(f2bf(((float)acc[mi][ni][e] * rs) * bf2f(g.sb[col_of(n + e)])));
             acc[mi][ni] = __builtin_bit_cast(acc_t, cf);
           }
         }
@@ -310,7 +313,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const GemmArgs g) {
   for (int mi = 0; mi < 8; ++mi) {
     const int m = wm * 128 + mi * 16 + frow;
     float rs = 1.f;
-    if constexpr (I8) rs = bf2f(g.E2[min(m0 + m, g.M - 1)]);  // A_scale_rowwise[m]
+    if constexpr (I8) rs = bf2f(g.sa[min(m0 + m, g.M - 1)]);  // A_scale_rowwise[m]
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
       const int n = wn * 64 + ni * 16 + fq * 4;
@@ -323,7 +326,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const GemmArgs g) {
         } else {
           // acc.to(fp32) * a_scale * b_scale, one rounding to the scale dtype (subclasses/int8_mm.py:112-118)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) c[e] = ((float)acc[mi][ni][e] * rs) * bf2f(g.E[min(n0 + n + e, g.N - 1)]);
+          for (int e = 0; e < 4; ++e) c[e] = ((float)acc[mi][ni][e] * rs) * bf2f(g.sb[col_of(n + e)]);
         }
       } else {
 #pragma unroll
@@ -468,6 +471,7 @@ static int gemm_nt_bf16_impl(const void* A, int64_t lda, const void* B, int64_t 
   a.M = (int)M; a.N = (int)N; a.K = (int)K; a.K2 = (int)K2;
   a.grid_m = (int)cdiv64(M, BM); a.grid_n = (int)cdiv64(N, BN);
   a.rope = rope; a.rope_S = (int)rope_S; a.rope_cols = (int)rope_cols;
+  a.sa = nullptr; a.sb = nullptr;
   switch (epilogue) {
     case EPI_NONE: return launch_gemm<EPI_NONE>(a, stream);
     case EPI_RESIDUAL: return launch_gemm<EPI_RESIDUAL>(a, stream);
@@ -513,7 +517,7 @@ extern "C" int llx_int8_mm_dequant(const void* A, int64_t lda, const void* B, in
   LLX_REQUIRE(((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) % 16 == 0, "llx_int8_mm_dequant: pointers must be 16-byte aligned");
   GemmArgs a;
   a.A = (const bf16_t*)A; a.B = (const bf16_t*)B; a.C = (bf16_t*)C; a.A2 = nullptr; a.B2 = nullptr;
-  a.E = (const bf16_t*)b_scale; a.E2 = (const bf16_t*)a_scale;
+  a.E = nullptr; a.E2 = nullptr; a.sa = (const bf16_t*)a_scale; a.sb = (const bf16_t*)b_scale;
   a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.lde = 0; a.lda2 = 0; a.ldb2 = 0;
   a.M = (int)M; a.N = (int)N; a.K = (int)K; a.K2 = 0;
   a.grid_m = (int)cdiv64(M, BM); a.grid_n = (int)cdiv64(N, BN);
@@ -521,26 +525,40 @@ extern "C" int llx_int8_mm_dequant(const void* A, int64_t lda, const void* B, in
   return launch_gemm<EPI_ROWCOLSCALE, true>(a, stream);
 }
 
-// torchao::int8_mm_dequant followed by a LoRA term in the same launch (an int8 base with dynamically quantised activations and a
-// bf16 adapter, subclasses/int8.py:110-118 + modelling/lora.py:43): C = bf16( bf16(int8_mm_dequant(A, B, a_scale, b_scale)) +
-// A2[M,K2].B2[N,K2]^T ) with A2/B2 bf16 and K2 a multiple of 64; the int32 accumulators are dequantised in place and the
-// extension accumulates on top in fp32.
+// torchao::int8_mm_dequant with the neighbours of its call sites fused in (an int8 base with dynamically quantised activations,
+// subclasses/int8.py:110-118): C = epilogue( bf16( bf16(int8_mm_dequant(A, B, a_scale, b_scale)) + A2[M,K2].B2[N,K2]^T ) ).
+//   A2/B2 (nullable, bf16, K2 % 64 == 0): the LoRA adapter (modelling/lora.py:43) - the int32 accumulators are dequantised in place
+//   and the extension accumulates on top in fp32;
+//   epilogue: 0 none | 1 + E[M,N] (residual, ld = lde) | 7 SwiGLU forward (B = [W_gate; W_up], E = OUTPUT h) | 8 RoPE on columns
+//   [0, rope_cols) (as llx_gemm_nt_bf16 / llx_gemm_nt_bf16_rope).
 extern "C" int llx_int8_mm_dequant_ext(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M, int64_t N,
                                        int64_t K, const void* a_scale, const void* b_scale, const void* A2, int64_t lda2, const void* B2,
-                                       int64_t ldb2, int64_t K2, hipStream_t stream) {
-  LLX_REQUIRE(A && B && C && a_scale && b_scale && A2 && B2, "llx_int8_mm_dequant_ext: null pointer");
-  LLX_REQUIRE(M > 0 && N > 0 && K > 0 && K2 > 0, "llx_int8_mm_dequant_ext: empty problem");
+                                       int64_t ldb2, int64_t K2, int epilogue, const void* E, int64_t lde, const float* rope_table,
+                                       int64_t rope_S, int64_t rope_cols, hipStream_t stream) {
+  LLX_REQUIRE(A && B && C && a_scale && b_scale, "llx_int8_mm_dequant_ext: null pointer");
+  LLX_REQUIRE(M > 0 && N > 0 && K > 0 && K2 >= 0, "llx_int8_mm_dequant_ext: empty problem");
   LLX_REQUIRE(K % 128 == 0 && K2 % 64 == 0, "llx_int8_mm_dequant_ext: K=%lld must be a multiple of 128 and K2=%lld of 64", (long long)K, (long long)K2);
   LLX_REQUIRE(N % 8 == 0 && ldc % 8 == 0, "llx_int8_mm_dequant_ext: N and ldc must be multiples of 8");
-  LLX_REQUIRE(lda % 16 == 0 && ldb % 16 == 0 && lda2 % 8 == 0 && ldb2 % 8 == 0, "llx_int8_mm_dequant_ext: row strides (int8: multiples of 16, bf16: of 8)");
-  LLX_REQUIRE(((uintptr_t)A | (uintptr_t)B | (uintptr_t)C | (uintptr_t)A2 | (uintptr_t)B2) % 16 == 0, "llx_int8_mm_dequant_ext: pointers must be 16-byte aligned");
-  LLX_REQUIRE(gemm_pipe_mode() == 1, "llx_int8_mm_dequant_ext: needs the four-phase main loop (LLX_GEMM_PIPE unset or 1)");
+  LLX_REQUIRE(lda % 16 == 0 && ldb % 16 == 0, "llx_int8_mm_dequant_ext: int8 row strides must be multiples of 16");
+  LLX_REQUIRE(((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) % 16 == 0, "llx_int8_mm_dequant_ext: pointers must be 16-byte aligned");
+  LLX_REQUIRE(K2 == 0 || (A2 && B2 && lda2 % 8 == 0 && ldb2 % 8 == 0 && ((uintptr_t)A2 | (uintptr_t)B2) % 16 == 0), "llx_int8_mm_dequant_ext: bad K-extension operands");
+  LLX_REQUIRE(epilogue == EPI_NONE || epilogue == EPI_RESIDUAL || epilogue == EPI_SWIGLU_FWD || epilogue == EPI_ROPE, "llx_int8_mm_dequant_ext: epilogue %d unsupported", epilogue);
+  LLX_REQUIRE(epilogue == EPI_NONE || epilogue == EPI_ROPE || (E && (uintptr_t)E % 16 == 0 && lde % 8 == 0), "llx_int8_mm_dequant_ext: epilogue operand missing/unaligned");
+  LLX_REQUIRE(epilogue != EPI_ROPE || (rope_table && (uintptr_t)rope_table % 16 == 0 && rope_S > 0 && rope_cols >= 0 && rope_cols <= N && rope_cols % 128 == 0),
+              "llx_int8_mm_dequant_ext: bad RoPE arguments");
+  LLX_REQUIRE(epilogue != EPI_SWIGLU_FWD || N % 256 == 0, "llx_int8_mm_dequant_ext: the SwiGLU epilogue needs N = 2I with I a multiple of 128");
+  LLX_REQUIRE(K2 == 0 || gemm_pipe_mode() == 1, "llx_int8_mm_dequant_ext: the K-extension needs the four-phase main loop (LLX_GEMM_PIPE unset or 1)");
   GemmArgs a;
   a.A = (const bf16_t*)A; a.B = (const bf16_t*)B; a.C = (bf16_t*)C; a.A2 = (const bf16_t*)A2; a.B2 = (const bf16_t*)B2;
-  a.E = (const bf16_t*)b_scale; a.E2 = (const bf16_t*)a_scale;
-  a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.lde = 0; a.lda2 = lda2; a.ldb2 = ldb2;
+  a.E = (const bf16_t*)E; a.E2 = nullptr; a.sa = (const bf16_t*)a_scale; a.sb = (const bf16_t*)b_scale;
+  a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.lde = lde; a.lda2 = lda2; a.ldb2 = ldb2;
   a.M = (int)M; a.N = (int)N; a.K = (int)K; a.K2 = (int)K2;
   a.grid_m = (int)cdiv64(M, BM); a.grid_n = (int)cdiv64(N, BN);
-  a.rope = nullptr; a.rope_S = 0; a.rope_cols = 0;
-  return launch_gemm<EPI_ROWCOLSCALE, true>(a, stream);
+  a.rope = rope_table; a.rope_S = (int)rope_S; a.rope_cols = (int)rope_cols;
+  switch (epilogue) {
+    case EPI_RESIDUAL: return launch_gemm<EPI_RESIDUAL, true>(a, stream);
+    case EPI_ROPE: return launch_gemm<EPI_ROPE, true>(a, stream);
+    case EPI_SWIGLU_FWD: a.grid_n = (int)(N / 256); return launch_gemm<EPI_SWIGLU_FWD, true>(a, stream);
+    default: return launch_gemm<EPI_ROWCOLSCALE, true>(a, stream);
+  }
 }

@@ -46,7 +46,7 @@ SIGNATURES: dict[str, tuple] = {
     "llx_i8_to_bf16": (c_int, [_P, _P, _L, _P]),
     "llx_quantize_int8_rowwise": (c_int, [_P, _L, _P, _L, _P, _L, _L, _I, _P]),
     "llx_int8_mm_dequant": (c_int, [_P, _L, _P, _L, _P, _L, _L, _L, _L, _P, _P, _P]),
-    "llx_int8_mm_dequant_ext": (c_int, [_P, _L, _P, _L, _P, _L, _L, _L, _L, _P, _P, _P, _L, _P, _L, _L, _P]),
+    "llx_int8_mm_dequant_ext": (c_int, [_P, _L, _P, _L, _P, _L, _L, _L, _L, _P, _P, _P, _L, _P, _L, _L, _I, _P, _L, _P, _L, _L, _P]),
     "llx_mel_spectrogram": (c_int, [_P, _L, _L, _P, _P, _P, _P, _L, _L, _L, _P]),
     "llx_logmel_cmn": (c_int, [_P, _P, _L, _L, _L, _P]),
     "llx_gelu_fwd": (c_int, [_P, _L, _P, _L, _L, _L, _P]),

@@ -233,7 +233,7 @@ class GroupPlan:
 
     def rope_fusable(self) -> bool:
         """apply_rope can ride in the projection GEMM's epilogue (one fused bf16 GEMM writes the whole q|k|v row)."""
-        return self.fused and not self.int8
+        return self.fused and (not self.int8 or self.dynamic)
 
     def _forward(self, x: Tensor, out: Tensor, residual: Optional[Tensor], swiglu_h: Optional[Tensor] = None,
                  rope: Optional[tuple[Tensor, int, int]] = None):
@@ -259,13 +259,15 @@ class GroupPlan:
             from subclasses.int8_mm import _launch as i8_gemm
 
             xi, xs = quantize_int8_rowwise(x)
-            if self.R > 0:  # the adapter rides in the int8 GEMM: int32 accumulators dequantised in place, then the bf16 K-extension
-                y0 = i8_gemm(xi, self.w_cat(), xs, self.scale_cat(), out=out if residual is None else None, a2=t[0], b2=b2)
-                if residual is not None:
-                    K.add(y0, residual, out=out)
-                return t
-            direct = residual is None
-            y0 = i8_gemm(xi, self.w_cat(), xs, self.scale_cat(), out=out if direct else None)
+            # one launch: int8 product dequantised in place, the adapter as bf16 K-extension, then residual / SwiGLU / RoPE epilogue
+            a2, bb = (t[0], b2) if self.R > 0 else (None, None)
+            if residual is not None:
+                i8_gemm(xi, self.w_cat(), xs, self.scale_cat(), out=out, a2=a2, b2=bb, epilogue=K.EPI_RESIDUAL, e=residual)
+            elif swiglu_h is not None:
+                i8_gemm(xi, self.w_cat(), xs, self.scale_cat(), out=out, a2=a2, b2=bb, epilogue=K.EPI_SWIGLU_FWD, e=swiglu_h)
+            else:
+                i8_gemm(xi, self.w_cat(), xs, self.scale_cat(), out=out, a2=a2, b2=bb, rope=rope)
+            return t
         else:
             direct = self.R == 0 and residual is None
             y0 = K.gemm_nt(x, self.w_cat(), out=out if direct else None, epilogue=K.EPI_COLSCALE, e=self.scale_cat())
@@ -550,7 +552,7 @@ class MLPBlockFn(Function):
             xn, rstd = x2, None
         T, I = x2.shape[0], meta.w13.Ns[0]
         gu = torch.empty(T, 2 * I, device=x.device, dtype=BF16)
-        if meta.w13.fused and not meta.w13.int8 and len(meta.w13.members) == 2 and I % 128 == 0 and _FUSE_SWIGLU_FWD:
+        if meta.w13.fused and (not meta.w13.int8 or meta.w13.dynamic) and len(meta.w13.members) == 2 and I % 128 == 0 and _FUSE_SWIGLU_FWD:
             h = torch.empty(T, I, device=x.device, dtype=BF16)
             _, t13 = meta.w13.forward(xn, gu, swiglu_h=h)  # SwiGLU in the epilogue of the gate|up GEMM
         else:

@@ -30,24 +30,43 @@ def _meta(A, B, A_scale_rowwise, B_scale_colwise):
 
 
 def _launch(A: Tensor, Bt: Tensor, a_scale: Tensor, b_scale: Tensor, out: Tensor | None = None, a2: Tensor | None = None,
-            b2: Tensor | None = None) -> Tensor:
+            b2: Tensor | None = None, epilogue: int = 0, e: Tensor | None = None, rope: tuple | None = None) -> Tensor:
     """A [M,K] int8 rows, Bt [N,K] int8 rows (= B^T), scales bf16 -> out [M,N] bf16.
-    a2 [M,K2], b2 [N,K2] (bf16, K2 % 64 == 0): a LoRA term a2 @ b2^T added on top of the dequantised product in the same launch."""
+    a2 [M,K2], b2 [N,K2] (bf16, K2 % 64 == 0): a LoRA term a2 @ b2^T added on top of the dequantised product in the same launch;
+    epilogue 1 (+ e [M,N]), 7 (SwiGLU forward, e = OUTPUT h [M,N/2]) or rope = (table, S, cols) as in llx.kernels.gemm_nt."""
     M, Kd = A.shape
     N = Bt.shape[0]
     if a_scale.dtype is not torch.bfloat16:
         raise L.LlxError(f"int8_mm_dequant: scales must be bf16 on the HIP path (got {a_scale.dtype})")
     if out is None:
         out = torch.empty(M, N, device=A.device, dtype=torch.bfloat16)
+    if a2 is None and epilogue == 0 and rope is None:
+        L.check(L.load().llx_int8_mm_dequant(L.ptr(A), A.stride(0), L.ptr(Bt), Bt.stride(0), L.ptr(out), out.stride(0), M, N, Kd,
+                                             L.ptr(a_scale), L.ptr(b_scale), L.stream()), "llx_int8_mm_dequant")
+        return out
+    K2 = 0
     if a2 is not None:
         assert b2 is not None and a2.dtype is torch.bfloat16 and b2.dtype is torch.bfloat16 and a2.shape == (M, b2.shape[1]) and b2.shape[0] == N
         assert a2.stride(1) == 1 and b2.stride(1) == 1
-        L.check(L.load().llx_int8_mm_dequant_ext(L.ptr(A), A.stride(0), L.ptr(Bt), Bt.stride(0), L.ptr(out), out.stride(0), M, N, Kd,
-                                                 L.ptr(a_scale), L.ptr(b_scale), L.ptr(a2), a2.stride(0), L.ptr(b2), b2.stride(0), a2.shape[1],
-                                                 L.stream()), "llx_int8_mm_dequant_ext")
-        return out
-    L.check(L.load().llx_int8_mm_dequant(L.ptr(A), A.stride(0), L.ptr(Bt), Bt.stride(0), L.ptr(out), out.stride(0), M, N, Kd,
-                                         L.ptr(a_scale), L.ptr(b_scale), L.stream()), "llx_int8_mm_dequant")
+        K2 = a2.shape[1]
+    lde, table, rs, rc = 0, None, 0, 0
+    if rope is not None:
+        assert epilogue == 0
+        table, rs, rc = rope
+        epilogue = 8
+        assert table.dtype is torch.float32 and table.is_contiguous() and table.shape[0] >= rs and table.shape[1:] == (64, 2)
+    elif epilogue == 1:
+        assert e is not None and e.shape == (M, N) and e.stride(1) == 1 and e.dtype is torch.bfloat16
+        lde = e.stride(0)
+    elif epilogue == 7:
+        assert e is not None and N % 256 == 0 and e.shape == (M, N // 2) and e.stride(1) == 1 and e.dtype is torch.bfloat16
+        lde = e.stride(0)
+    else:
+        assert epilogue == 0, f"int8 GEMM: epilogue {epilogue} unsupported"
+    L.check(L.load().llx_int8_mm_dequant_ext(L.ptr(A), A.stride(0), L.ptr(Bt), Bt.stride(0), L.ptr(out), out.stride(0), M, N, Kd,
+                                             L.ptr(a_scale), L.ptr(b_scale), L.ptr(a2), a2.stride(0) if a2 is not None else 0, L.ptr(b2),
+                                             b2.stride(0) if b2 is not None else 0, K2, epilogue, L.ptr(e), lde, L.ptr(table), rs, rc,
+                                             L.stream()), "llx_int8_mm_dequant_ext")
     return out
 
 

@@ -179,6 +179,40 @@ def test_int8_mm_dequant_with_lora_extension(K, cuda, M, N, Kd, K2):
     torch.testing.assert_close(one.float(), two.float(), atol=tol, rtol=2 ** -6)
 
 
+@pytest.mark.parametrize("K2", [0, 64])
+def test_int8_mm_dequant_fused_epilogues(K, cuda, K2):
+    """Residual, RoPE and SwiGLU-forward epilogues on the int8 GEMM: without the adapter they equal the unfused sequence bit for
+    bit (the dequantised product is rounded to bf16 at the same point); with the adapter to bf16 rounding."""
+    from subclasses.int8_mm import _launch
+
+    M, I, Kd, S = 512, 768, 256, 256
+    N = 2 * I
+    a = O.randint("a", (M, Kd), -127, 128).to(torch.int8).to(cuda)
+    b = O.randint("b", (N, Kd), -127, 128).to(torch.int8).to(cuda)
+    sa = _bf(O.uniform("sa", (M,), 0.001, 0.01)).to(cuda)
+    sb = _bf(O.uniform("sb", (N,), 0.001, 0.01)).to(cuda)
+    a2 = _bf(O.randn("a2", (M, K2))).to(cuda) if K2 else None
+    b2 = _bf(O.randn("b2", (N, K2), 0.05)).to(cuda) if K2 else None
+    base = _launch(a, b, sa, sb, a2=a2, b2=b2)
+
+    def same(x, y):
+        if K2 == 0:
+            assert torch.equal(x, y)
+        else:
+            torch.testing.assert_close(x.float(), y.float(), atol=2 ** -7 * y.float().abs().max().item(), rtol=2 ** -6)
+
+    res = _bf(O.randn("res", (M, N))).to(cuda)
+    same(_launch(a, b, sa, sb, a2=a2, b2=b2, epilogue=K.EPI_RESIDUAL, e=res), K.add(base, res))
+    table = O.rope_table(O.TINY)[:S].contiguous().to(cuda)
+    roped = base.clone()
+    K.rope_(roped.view(M // S, S, N), table, 8)
+    same(_launch(a, b, sa, sb, a2=a2, b2=b2, rope=(table, S, 8 * 128)), roped)
+    h = torch.empty(M, I, device=cuda, dtype=torch.bfloat16)
+    gu = _launch(a, b, sa, sb, a2=a2, b2=b2, epilogue=K.EPI_SWIGLU_FWD, e=h)
+    same(gu, base)
+    same(h, K.swiglu_fwd(base[:, :I], base[:, I:]))
+
+
 def test_gemm_rejects_bad_shapes(K, cuda):
     from llx._lib import LlxError
 
