@@ -216,3 +216,35 @@ def test_product_fails_loudly_without_gpu():
         m(torch.zeros(1, 8, dtype=torch.int64))
     with pytest.raises(LlxError):
         m.layers[0].attention.wq(torch.zeros(1, 8, 128, dtype=torch.bfloat16))
+
+
+def test_group_plan_block_diagonal_descriptors():
+    """Host side of the block-diagonal LoRA operands: the k ranges (skinny_nt) and member segments (skinny_tn) that a fused
+    linear group hands to the kernels."""
+    from torch import nn
+
+    from llx.ops import GroupPlan
+    from modelling import apply_linear_adapter_
+
+    def group(ns, rank, k=256):
+        mods = nn.ModuleList([nn.Linear(k, n, bias=False) for n in ns]).bfloat16()
+        apply_linear_adapter_(mods, "lora", rank=rank, alpha=float(rank))
+        return GroupPlan(list(mods))
+
+    g = group((4096, 1024, 1024), 16)  # q|k|v at 8B dims
+    assert g.fused and g.R == 48
+    assert g._kranges() == [0, 4096, 4096, 5120, 5120, 6144, 0, 0]
+    assert g._tn_segs() == [(0, 4096, 0, 16), (4096, 5120, 16, 32), (5120, 6144, 32, 48)]
+    g = group((14336, 14336), 16)  # gate|up
+    assert g._kranges() == [0, 14336, 14336, 28672, 0, 0, 0, 0]
+    assert g._tn_segs() == [(0, 14336, 0, 16), (14336, 28672, 16, 32)]
+    g = group((512, 512), 8)  # two rank-8 members share the first 16-row block of B^T: its k range is their union
+    assert g._kranges() == [0, 1024, 0, 0, 0, 0, 0, 0]
+    assert g._tn_segs() == [(0, 512, 0, 8), (512, 1024, 8, 16)]
+    g = group((512, 128, 128), 16)  # tiny config: member boundaries at multiples of 64 but not of 256
+    assert g._kranges() == [0, 512, 512, 640, 640, 768, 0, 0]
+    assert g._tn_segs() is None  # skinny_tn falls back to the full [N, R] product and slices
+    g = group((4096,), 16)  # a single member's B^T is dense
+    assert g._kranges() is None and g._tn_segs() == [(0, 4096, 0, 16)]
+    g = group((200, 312), 16)  # boundary not a multiple of 64: dense
+    assert g._kranges() is None and g._tn_segs() is None
