@@ -523,36 +523,37 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv3_kernel(const AttnBwdArgs
   const char* qbase = (const char*)(a.q + (int64_t)b * a.q_sb + h * HD);
   const char* dbase = (const char*)(a.d_o + (int64_t)b * a.do_sb + h * HD);
   const float* lbase = (wave == 0 ? a.nlse : a.delta) + ((int64_t)b * a.H + h) * a.S;
-  // One LDS-DMA piece = 1 KiB = 4 rows of one image per wave-instruction; piece p < 8: image p&1 (Q / dO), row group p>>1;
-  // piece 8: the row statistics (waves 0 and 1).  (Spreading the pieces between the MFMAs of the first S chain instead of
-  // bursting them at the top of the tile was tried: hipcc then spills ~120 registers; the burst costs ~1.4k cycles per tile.)
-  auto stage_piece = [&](int buf, int qt, int p) {
+  // One LDS-DMA piece = 1 KiB = 4 rows of one image per wave-instruction: 4 row groups x {Q, dO} per wave, plus the row
+  // statistics (waves 0 and 1).  The lane offsets are rebuilt once per call from a fresh lane id (kept across the loop they would
+  // be spilled).  (Spreading the pieces between the MFMAs of the first S chain instead of bursting them at the top of the tile was
+  // tried: hipcc then spills ~120 registers; the burst costs ~1.4k cycles per tile.)
+  auto stage = [&](int buf, int qt) {
     uint32_t ln;
     asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
-    if (p == 8) {
-      if (wave < 2) {  // wave 0: -lse[64] (sanitised), wave 1: delta[64]
-        const float* src = lbase + min(qt * DKV_QT + (int)ln, a.S - 1);
-        __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)((lds_char*)smem + 0x10000 + buf * 512 + wave * 256), 4, 0, 0);
-      }
-      return;
-    }
-    const int img = p & 1, i = p >> 1;
     const uint32_t srow = wave * 4 + (ln >> 4);
     const uint32_t sc = (ln & 15) ^ dual_swz(srow);
-    lds_char* dst = (lds_char*)smem + buf * 0x8000 + img * 0x4000 + i * 4096 + wave * 1024;
-    const char* base = img ? dbase : qbase;
-    const int64_t ss = img ? a.do_ss : a.q_ss;
+    lds_char* sQ = (lds_char*)smem + buf * 0x8000 + wave * 1024;
     if (qt * DKV_QT + DKV_QT <= a.S) {
-      const char* u = base + (int64_t)(qt * DKV_QT + i * 16) * ss * 2;  // wave-uniform
-      __builtin_amdgcn_global_load_lds((gbl_void*)(u + (srow * (uint32_t)ss + sc * 8) * 2), (lds_void*)dst, 16, 0, 0);
-    } else {  // ragged last tile: clamp the row per lane
-      const int qr = min(qt * DKV_QT + i * 16 + (int)srow, a.S - 1);
-      __builtin_amdgcn_global_load_lds((gbl_void*)(base + ((int64_t)qr * ss + sc * 8) * 2), (lds_void*)dst, 16, 0, 0);
-    }
-  };
-  auto stage = [&](int buf, int qt) {
+      const uint32_t q_lane = (srow * (uint32_t)a.q_ss + sc * 8) * 2, d_lane = (srow * (uint32_t)a.do_ss + sc * 8) * 2;
 #pragma unroll
-    for (int p = 0; p < 9; ++p) stage_piece(buf, qt, p);
+      for (int i = 0; i < 4; ++i) {
+        const char* qu = qbase + (int64_t)(qt * DKV_QT + i * 16) * a.q_ss * 2;   // wave-uniform
+        const char* du = dbase + (int64_t)(qt * DKV_QT + i * 16) * a.do_ss * 2;
+        __builtin_amdgcn_global_load_lds((gbl_void*)(qu + q_lane), (lds_void*)(sQ + i * 4096), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_void*)(du + d_lane), (lds_void*)(sQ + 0x4000 + i * 4096), 16, 0, 0);
+      }
+    } else {  // ragged last tile: clamp the row per lane
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int qr = min(qt * DKV_QT + i * 16 + (int)srow, a.S - 1);
+        __builtin_amdgcn_global_load_lds((gbl_void*)(qbase + ((int64_t)qr * a.q_ss + sc * 8) * 2), (lds_void*)(sQ + i * 4096), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_void*)(dbase + ((int64_t)qr * a.do_ss + sc * 8) * 2), (lds_void*)(sQ + 0x4000 + i * 4096), 16, 0, 0);
+      }
+    }
+    if (wave < 2) {  // wave 0: -lse[64] (sanitised), wave 1: delta[64]
+      const float* src = lbase + min(qt * DKV_QT + (int)ln, a.S - 1);
+      __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)((lds_char*)smem + 0x10000 + buf * 512 + wave * 256), 4, 0, 0);
+    }
   };
 
   f32x16_t dk[4], dv[4];
