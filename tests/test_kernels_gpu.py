@@ -213,6 +213,49 @@ def test_int8_mm_dequant_fused_epilogues(K, cuda, K2):
     same(h, K.swiglu_fwd(base[:, :I], base[:, I:]))
 
 
+def test_fused_epilogues_random_shapes(K, cuda):
+    """Seeded sweep over ragged shapes: every fused epilogue must reproduce its unfused sequence bit for bit (M not a multiple of
+    the tile, several column tiles, K-extension on and off, more than one sequence per batch for the RoPE positions)."""
+    import random
+
+    rnd = random.Random(7)
+    for it in range(8):
+        Sq = rnd.choice([96, 200, 256, 333])
+        Bn = rnd.choice([1, 2, 3])
+        M = Sq * Bn
+        D = 64 * rnd.randint(1, 6)
+        K2 = rnd.choice([0, 64])
+        I = 128 * rnd.randint(1, 9)
+        heads = rnd.randint(1, 5)
+        W = (heads + 2) * 128
+        x = _bf(O.randn(f"x{it}", (M, D))).to(cuda)
+        a2 = _bf(O.randn(f"a2{it}", (M, K2))).to(cuda) if K2 else None
+        # RoPE epilogue on the first `heads` heads of a [M, W] projection
+        w = _bf(O.randn(f"w{it}", (W, D), 0.05)).to(cuda)
+        b2 = _bf(O.randn(f"b2{it}", (W, K2), 0.05)).to(cuda) if K2 else None
+        table = O.rope_table(O.TINY)[:Sq].contiguous().to(cuda)
+        ref = K.gemm_nt(x, w, a2=a2, b2=b2)
+        K.rope_(ref.view(Bn, Sq, W), table, heads)
+        out = K.gemm_nt(x, w, a2=a2, b2=b2, rope=(table, Sq, heads * 128))
+        assert torch.equal(out, ref), ("rope", it, M, D, W, K2)
+        # SwiGLU forward / backward epilogues
+        w13 = _bf(O.randn(f"w13{it}", (2 * I, D), 0.05)).to(cuda)
+        b13 = _bf(O.randn(f"b13{it}", (2 * I, K2), 0.05)).to(cuda) if K2 else None
+        gu_ref = K.gemm_nt(x, w13, a2=a2, b2=b13)
+        h_ref = K.swiglu_fwd(gu_ref[:, :I], gu_ref[:, I:])
+        gu, h = torch.empty_like(gu_ref), torch.empty_like(h_ref)
+        K.gemm_nt(x, w13, out=gu, a2=a2, b2=b13, epilogue=K.EPI_SWIGLU_FWD, e=h)
+        assert torch.equal(gu, gu_ref) and torch.equal(h, h_ref), ("swiglu fwd", it, M, D, I, K2)
+        wt = _bf(O.randn(f"wt{it}", (I, D), 0.05)).to(cuda)
+        bt = _bf(O.randn(f"bt{it}", (I, K2), 0.05)).to(cuda) if K2 else None
+        dh = K.gemm_nt(x, wt, a2=a2, b2=bt)
+        dref = torch.empty(M, 2 * I, device=cuda, dtype=torch.bfloat16)
+        K.swiglu_bwd(dh, gu_ref[:, :I], gu_ref[:, I:], dref[:, :I], dref[:, I:])
+        dgu = torch.empty_like(dref)
+        K.gemm_nt(x, wt, out=dgu, a2=a2, b2=bt, epilogue=K.EPI_SWIGLU_BWD, e=gu_ref)
+        assert torch.equal(dgu, dref), ("swiglu bwd", it, M, D, I, K2)
+
+
 def test_gemm_rejects_bad_shapes(K, cuda):
     from llx._lib import LlxError
 
