@@ -452,6 +452,36 @@ def test_attention_fwd_bwd(K, cuda, B, S, H, KVH, kind):
     torch.testing.assert_close(dv.cpu().float(), vr.grad, atol=4e-2, rtol=4e-2)
 
 
+def test_attention_random_shapes(K, cuda):
+    """Seeded sweep of sequence lengths that are not tile multiples, batch sizes, GQA ratios and mask kinds against the oracle's
+    dense-mask attention (evaluated in fp32 on the device through the oracle's own function)."""
+    import random
+
+    rnd = random.Random(11)
+    for it in range(10):
+        B = rnd.choice([1, 2, 3])
+        S = rnd.choice([130, 197, 320, 449, 705, 1024])
+        KVH = rnd.choice([1, 2])
+        H = KVH * rnd.choice([1, 2, 4])
+        kind = rnd.choice(["causal", "doc", "prefix", "docprefix"])
+        q = _bf(O.randn(f"q{it}", (B, S, H, 128))).to(cuda)
+        k = _bf(O.randn(f"k{it}", (B, S, KVH, 128))).to(cuda)
+        v = _bf(O.randn(f"v{it}", (B, S, KVH, 128))).to(cuda)
+        do = _bf(O.randn(f"do{it}", (B, S, H, 128))).to(cuda)
+        mask, doc, prefix = _masks(kind, B, S)
+        qr, kr, vr = (t.float().requires_grad_() for t in (q, k, v))
+        ref = O.sdpa(qr.transpose(1, 2), kr.transpose(1, 2), vr.transpose(1, 2), mask.to(cuda)).transpose(1, 2)
+        ref.backward(do.float())
+        ms = K.MaskSpec(doc, prefix) if (doc is not None or prefix is not None) else None
+        o, lse = K.attn_fwd(q, k, v, ms)
+        tag = (it, B, S, H, KVH, kind)
+        torch.testing.assert_close(o.float(), ref.detach(), atol=2e-2, rtol=2e-2, msg=lambda m: f"{tag}: {m}")
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        K.attn_bwd(q, k, v, o, do, lse, dq, dk, dv, ms)
+        for name, got, want in (("dq", dq, qr.grad), ("dk", dk, kr.grad), ("dv", dv, vr.grad)):
+            torch.testing.assert_close(got.float(), want, atol=5e-2, rtol=5e-2, msg=lambda m, n=name: f"{tag} {n}: {m}")
+
+
 def test_attention_mask_bits_exact(K, cuda):
     """The mask rule itself is integer work: with V = one-hot-ish rows the set of attended keys is recovered exactly."""
     B, S, H = 1, 256, 1
