@@ -119,7 +119,7 @@ def main():
     ap.add_argument("--seq", type=int, default=4096)
     ap.add_argument("--rank", type=int, default=16)
     ap.add_argument("--model", default="llama31_8b", choices=["llama31_8b", "tiny"])
-    ap.add_argument("--config", default="text", choices=["text", "int8", "audio"],
+    ap.add_argument("--config", default="text", choices=["text", "int8", "audio", "packed"],
                     help="text: BASELINE configs[1] (headline); int8: configs[3] per-GPU (INT8 frozen base, dynamic int8 activations, i8 MFMA) ; "
                          "audio: configs[2] (mel+Conv1D prefix of seq/2 audio tokens + seq/2 text tokens, prefix-LM mask, audio_embed trainable)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -163,6 +163,24 @@ def main():
 
         audio_buf = (torch.rand(1, St * 320, device=device, generator=gen) - 0.5) * 0.2
         prefix_mask = MaskSpec(prefix_len=torch.tensor([St], device=device, dtype=torch.int32))
+    doc_mask = None
+    if args.config == "packed":
+        # packed documents (train_metamathqa.py:51-83): lengths ~ clipped log-normal (median ~190, P99 ~680, max 2318 tokens as the
+        # MetaMathQA statistics of SURVEY 8d), packed greedily into the S-token buffer; the unused tail keeps id 0 (packer quirk)
+        import numpy as np
+        from modelling.llama import MaskSpec
+
+        rng = np.random.default_rng(1234 + rank)
+        ids_np, pos, doc = np.zeros(S, dtype=np.int32), 0, 0
+        while True:
+            n = int(min(2318, max(16, rng.lognormal(mean=5.25, sigma=0.55))))
+            if pos + n > S:
+                break
+            doc += 1
+            ids_np[pos : pos + n] = doc
+            pos += n
+        n_docs = doc
+        doc_mask = MaskSpec(doc_ids=torch.from_numpy(ids_np).to(device))
 
     def batch():
         ids = torch.randint(0, cfg.vocab_size, (1, St), device=device, generator=gen)
@@ -174,6 +192,8 @@ def main():
     def run_model(ids, labels):
         if audio_cfg:
             return model(audio_buf, ids, labels=labels, block_mask=prefix_mask)
+        if doc_mask is not None:
+            return model(ids, labels=labels, block_mask=doc_mask)
         return model(ids, labels=labels)
 
     def eager_step():
@@ -284,6 +304,8 @@ def main():
                                              "(BASELINE.json configs[1]); random-init weights at 8B dimensions",
                                      "int8": f"Llama-3.1-8B INT8 frozen base (dynamic int8 activations, i8 MFMA int8_mm_dequant) + bf16 LoRA r={args.rank}, seq={S}, "
                                              "1 sequence per GPU (BASELINE.json configs[3] per-GPU workload)",
+                                     "packed": f"Llama-3.1-8B text-only LoRA r={args.rank} bf16, seq={S} packed from {n_docs if args.config == 'packed' else 0} synthetic documents "
+                                               "(log-normal lengths), document mask (BASELINE.json configs[1], packed variant of SURVEY 8d C2)",
                                      "audio": f"Llama-3.1-8B + mel/Conv1D audio prefix ({St} audio tokens from {St * 320} samples) + {St} text tokens, prefix-LM mask, "
                                               f"LoRA r={args.rank} + trainable audio_embed (BASELINE.json configs[2])"}[args.config]
                                     if args.model == "llama31_8b" else f"tiny plumbing config seq={S} ({args.config})"),

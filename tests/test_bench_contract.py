@@ -17,7 +17,7 @@ def test_cli_help():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("extra", [[], ["--config", "int8"], ["--config", "audio", "--no-graph"]])
+@pytest.mark.parametrize("extra", [[], ["--config", "int8"], ["--config", "audio", "--no-graph"], ["--config", "packed"]])
 def test_tiny_bench_line(cuda, extra):
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--model", "tiny", "--seq", "512", "--steps", "3", "--warmup", "2", "--no-cpu-baseline"] + extra
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
