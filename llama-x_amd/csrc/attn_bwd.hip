@@ -13,7 +13,6 @@
 //               dK^T += Q^T.dS with P/dS from the accumulator registers and Q^T/dO^T by transposed LDS reads.
 // LDS images read both by rows and transposed use the dual-use swizzle  slot = chunk ^ (((row&3)<<2) | ((row>>2)&3)).
 #include "common.h"
-#include <cstdlib>
 
 #define HD 128
 #define BQ 128
@@ -245,220 +244,22 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnBwdArgs a
 
 // ------------------------------------------------------------------------------------------ dK, dV
 #define DKV_QT 64
-#define DKV_STAGE_BYTES (2 * TILE_BYTES + 512)  // Q tile + dO tile + lse[64] + delta[64]
-#define DKV_LDS_BYTES (2 * DKV_STAGE_BYTES)
-
-// One workgroup = 4 waves = 128 keys of ONE query head: a wave owns 32 keys, K/V fragments in registers, dK^T/dV^T in
-// 128 accumulator registers; heaviest key blocks are dispatched first under the causal mask, two workgroups per CU
-// (<= 256 registers) so one wave's softmax VALU overlaps its SIMD partner's MFMAs.
-// The G per-head fp32 partials are summed by attn_dkv_reduce_kernel (deterministic, no atomics).
+// One workgroup = 4 waves = 128 keys of ONE query head: a wave owns 32 keys, K/V fragments in registers, dK^T/dV^T in 128
+// accumulator registers; heaviest key blocks are dispatched first under the causal mask, two workgroups per CU (<= 256
+// registers) so one wave's softmax VALU overlaps its SIMD partner's MFMAs.  The G per-head fp32 partials are summed by
+// attn_dkv_reduce_kernel (deterministic, no atomics).
 #define DKV2_KEYS 128
 
-template <bool GENERAL>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkv2_kernel(const AttnBwdArgs a, float* __restrict__ part) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nqb = (a.S + BQ - 1) / BQ, nkt = (a.S + BKV - 1) / BKV;
-  const int nqt = (a.S + DKV_QT - 1) / DKV_QT;
-  const int G = a.H / a.KVH;
-  // 1-D grid, key block slowest: the heaviest blocks (lowest keys under a causal mask) are dispatched first
-  int id = blockIdx.x;
-  const int per_kb = a.B * a.KVH * G;
-  const int kblk = id / per_kb;
-  id -= kblk * per_kb;
-  const int b = id / (a.KVH * G);
-  id -= b * (a.KVH * G);
-  const int kvh = id / G, g = id % G;
-  const int h = kvh * G + g;
-  const int r = lane & 31, hh = lane >> 5;
-  const int key = kblk * DKV2_KEYS + wave * 32 + r;
-  const int krow = min(key, a.S - 1);
-  const int my_kt = 2 * kblk + (wave >> 1);
-
-  bf16x8_t kf[8], vf[8];
-  {
-    const bf16_t* kp = a.k + (int64_t)b * a.k_sb + (int64_t)krow * a.k_ss + kvh * HD + 8 * hh;
-    const bf16_t* vp = a.v + (int64_t)b * a.v_sb + (int64_t)krow * a.v_ss + kvh * HD + 8 * hh;
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
-      kf[ks] = *reinterpret_cast<const bf16x8_t*>(kp + 16 * ks);
-      vf[ks] = *reinterpret_cast<const bf16x8_t*>(vp + 16 * ks);
-    }
-  }
-  const int* docrow = (GENERAL && a.doc_ids) ? a.doc_ids + (int64_t)b * a.S : nullptr;
-  const int key_doc = docrow ? docrow[krow] : 0;
-  const int my_prefix = (GENERAL && a.prefix_len) ? a.prefix_len[b] : 0;
-
-  const int qt_first = GENERAL ? 0 : (kblk * DKV2_KEYS) / DKV_QT;
-  auto block_class = [&](int qt, int kt) -> int {
-    if (kt >= nkt) return 0;
-    if constexpr (GENERAL) return a.flags[((int64_t)b * nqb + (qt >> 1)) * nkt + kt];
-    const int q_lo = qt * DKV_QT, q_hi = q_lo + DKV_QT - 1, k_lo = kt * BKV, k_hi = k_lo + BKV - 1;
-    if (k_lo > q_hi) return 0;
-    return (k_hi <= q_lo) ? 2 : 1;
-  };
-  auto next_qt = [&](int qt) {
-    while (qt < nqt && !(qt >= qt_first && (block_class(qt, 2 * kblk) != 0 || block_class(qt, 2 * kblk + 1) != 0))) ++qt;
-    return qt;
-  };
-
-  const int srow_in = lane >> 4, sslot = lane & 15;
-  const bf16_t* qbase = a.q + (int64_t)b * a.q_sb + h * HD;
-  const bf16_t* dbase = a.d_o + (int64_t)b * a.do_sb + h * HD;
-  auto stage = [&](int buf, int qt) {
-    char* sQ = smem + buf * DKV_STAGE_BYTES;
-    char* sD = sQ + TILE_BYTES;
-    char* sL = sD + TILE_BYTES;
-    // (addresses are recomputed per tile on purpose: hoisting them costs 8 VGPRs and pushes this kernel into scratch)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = i * 16 + wave * 4 + srow_in;
-      const int qr = min(qt * DKV_QT + row, a.S - 1);
-      const int c = sslot ^ dual_swz(row);
-      __builtin_amdgcn_global_load_lds((gbl_void*)(qbase + (int64_t)qr * a.q_ss + c * 8), (lds_void*)(sQ + (i * 16 + wave * 4) * 256), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gbl_void*)(dbase + (int64_t)qr * a.do_ss + c * 8), (lds_void*)(sD + (i * 16 + wave * 4) * 256), 16, 0, 0);
-    }
-    if (wave < 2) {  // wave 0: lse[64], wave 1: delta[64]
-      const float* src = (wave == 0 ? a.lse : a.delta) + ((int64_t)b * a.H + h) * a.S + min(qt * DKV_QT + lane, a.S - 1);
-      __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(sL + wave * 256), 4, 0, 0);
-    }
-  };
-
-  f32x16_t dk[4], dv[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) { dk[i][e] = 0.f; dv[i][e] = 0.f; }
-
-  int qt = next_qt(0);
-  if (qt < nqt) stage(0, qt);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  int cur = 0;
-  while (qt < nqt) {
-    const int qtn = next_qt(qt + 1);
-    if (qtn < nqt) stage(cur ^ 1, qtn);
-    const char* sQ = smem + cur * DKV_STAGE_BYTES;
-    const char* sD = sQ + TILE_BYTES;
-    const float* sL = reinterpret_cast<const float*>(sD + TILE_BYTES);
-    int cls = block_class(qt, my_kt);
-    if (cls == 2 && (qt * DKV_QT + DKV_QT > a.S)) cls = 1;
-    if (cls != 0) {
-#pragma unroll
-      for (int qb32 = 0; qb32 < 2; ++qb32) {
-        f32x16_t st, dp;
-        const f32x16_t zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        const int row = qb32 * 32 + r;
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-          st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(sQ, row, ks, hh), kf[ks], ks == 0 ? zero : st, 0, 0, 0);
-          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(sD, row, ks, hh), vf[ks], ks == 0 ? zero : dp, 0, 0, 0);
-        }
-#pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-          const int ql = qb32 * 32 + 8 * g4 + 4 * hh;
-          const f32x4_t l4 = *reinterpret_cast<const f32x4_t*>(sL + ql);
-          const f32x4_t d4 = *reinterpret_cast<const f32x4_t*>(sL + 64 + ql);
-#pragma unroll
-          for (int e2 = 0; e2 < 4; ++e2) {
-            const int e = 4 * g4 + e2;
-            const float lse = (l4[e2] == -INFINITY) ? 0.f : l4[e2];
-            float p = __builtin_amdgcn_exp2f(__builtin_fmaf(st[e], a.scale_log2, -lse));
-            if (cls != 2) {
-              const int qi = qt * DKV_QT + ql + e2;
-              bool ok = (qi < a.S) && (key < a.S) && (key <= qi || key < my_prefix);
-              if constexpr (GENERAL) {
-                const int qd = docrow ? docrow[min(qi, a.S - 1)] : key_doc;
-                ok = ok && (qd == key_doc);
-              }
-              p = ok ? p : 0.f;
-            }
-            st[e] = p;
-            dp[e] = p * (dp[e] - d4[e2]);
-          }
-        }
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-          bf16x8_t pb, dsb;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) { pb[j] = (__bf16)st[8 * s2 + j]; dsb[j] = (__bf16)dp[8 * s2 + j]; }
-#pragma unroll
-          for (int db = 0; db < 4; ++db) {
-            dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(sD, qb32 * 32 + s2 * 16, db, lane), pb, dv[db], 0, 0, 0);
-            dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(sQ, qb32 * 32 + s2 * 16, db, lane), dsb, dk[db], 0, 0, 0);
-          }
-        }
-      }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    cur ^= 1;
-    qt = qtn;
-  }
-
-  // fp32 partials: part[(g*2 + which) * B*S*KVH*128 + ((b*S + key)*KVH + kvh)*128 + d], which = 0 dK (unscaled), 1 dV
-  const int64_t plane = (int64_t)a.B * a.S * a.KVH * HD;
-  if (key < a.S) {
-    float* pk = part + (int64_t)(g * 2 + 0) * plane + (((int64_t)b * a.S + key) * a.KVH + kvh) * HD;
-    float* pv = part + (int64_t)(g * 2 + 1) * plane + (((int64_t)b * a.S + key) * a.KVH + kvh) * HD;
-#pragma unroll
-    for (int db = 0; db < 4; ++db)
-#pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        const int d = 32 * db + 8 * g4 + 4 * hh;
-        *reinterpret_cast<f32x4_t*>(pk + d) = f32x4_t{dk[db][4 * g4], dk[db][4 * g4 + 1], dk[db][4 * g4 + 2], dk[db][4 * g4 + 3]};
-        *reinterpret_cast<f32x4_t*>(pv + d) = f32x4_t{dv[db][4 * g4], dv[db][4 * g4 + 1], dv[db][4 * g4 + 2], dv[db][4 * g4 + 3]};
-      }
-  }
-}
-
-// ---- dkv3: the same algorithm as dkv2 with every LDS address written as  (lane constant ^ small constant) + immediate.
-// hipcc cannot see that the swizzled addresses of the 8 k-steps / 4 d-blocks differ by an XOR of the low byte, so in dkv2 it
-// keeps ~30 address registers live, spills them (124 B of scratch) and reloads them behind `s_waitcnt vmcnt(0)` - which also
-// waits for the NEXT tile's LDS-DMA and turns the prefetch synchronous.  LDS map (bytes, 256-aligned base):
+// Every LDS address is written as  (per-tile lane constant ^ small constant) + immediate.  hipcc cannot see that the swizzled
+// addresses of the 8 k-steps / 4 d-blocks differ by an XOR of the low byte; left to itself (the previous version of this kernel)
+// it kept ~30 address registers live, spilled them (124 B of scratch) and reloaded them behind `s_waitcnt vmcnt(0)` - which also
+// waits for the NEXT tile's LDS-DMA and turns the prefetch synchronous (505 -> 300 us per layer with this form).
+// LDS map (bytes, 256-aligned base):
 //   stage s: Q image s*0x8000, dO image s*0x8000 + 0x4000;  lse[64] at 0x10000 + s*512, delta[64] at 0x10100 + s*512.
 typedef __attribute__((address_space(3))) char lds_char;
 typedef __attribute__((address_space(3))) bf16x8_t lds_bf16x8;
 typedef __attribute__((address_space(3))) f32x4_t lds_f32x4;
 #define DKV3_LDS_BYTES (0x10000 + 1024)
-
-// ---- LDS reads hipcc does not count (guide: 'loads hipcc must not wait for').  A transposed-read intrinsic issued while the
-// next tile's LDS-DMA is in flight makes hipcc insert `s_waitcnt vmcnt(0)` (it cannot prove the two LDS regions disjoint), i.e.
-// the prefetch is drained in the middle of every tile.  As asm statements the reads are invisible to that bookkeeping; each
-// destination is named "+v" by the wait that precedes its first consumer, so no MFMA can be scheduled above the wait.
-template <int OFF>
-__device__ __forceinline__ void lds_rd128(u32x4_t& d, uint32_t addr) {
-  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
-}
-template <int OFF>
-__device__ __forceinline__ void lds_rdtr(u32x2_t& d, uint32_t addr) {
-  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
-}
-template <int N>
-__device__ __forceinline__ void lds_wait(u32x4_t& a, u32x4_t& b) {
-  asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N));
-}
-template <int N>
-__device__ __forceinline__ void lds_wait(u32x2_t& a, u32x2_t& b, u32x2_t& c, u32x2_t& d) {
-  asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N));
-}
-template <int N>
-__device__ __forceinline__ void lds_wait1(u32x4_t& a) {
-  asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a) : "n"(N));
-}
-__device__ __forceinline__ bf16x8_t frag_of(const u32x4_t& v) { return __builtin_bit_cast(bf16x8_t, v); }
-__device__ __forceinline__ bf16x8_t frag_of(const u32x2_t& lo, const u32x2_t& hi) {
-  const u32x4_t v = {lo[0], lo[1], hi[0], hi[1]};
-  return __builtin_bit_cast(bf16x8_t, v);
-}
-template <int I, int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-  if constexpr (I < N) {
-    f(std::integral_constant<int, I>{});
-    static_for<I + 1, N>(f);
-  }
-}
 
 // a ^ c issued where it is written: as plain C++ hipcc computes all the XORed addresses of a tile up front and keeps them live
 __device__ __forceinline__ uint32_t xor_imm(uint32_t a, int c) {
@@ -785,10 +586,10 @@ extern "C" int llx_attn_bwd(const void* q, int64_t q_sb, int64_t q_ss, const voi
   if (!g_bwd_attr) {
     hipError_t e1 = hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, DQ_LDS_BYTES);
     hipError_t e4 = hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, DQ_LDS_BYTES);
-    hipError_t e5 = hipFuncSetAttribute((const void*)attn_bwd_dkv2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS_BYTES);
+    hipError_t e5 = hipSuccess;
     hipError_t e2 = hipFuncSetAttribute((const void*)attn_bwd_dkv3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV3_LDS_BYTES);
     if (e2 == hipSuccess) e2 = hipFuncSetAttribute((const void*)attn_bwd_dkv3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV3_LDS_BYTES);
-    hipError_t e3 = hipFuncSetAttribute((const void*)attn_bwd_dkv2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS_BYTES);
+    hipError_t e3 = hipSuccess;
     if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess || e5 != hipSuccess) { llx_set_error("llx_attn_bwd: cannot raise LDS limit"); return LLX_ERR_LAUNCH; }
     g_bwd_attr = true;
   }
@@ -807,19 +608,13 @@ extern "C" int llx_attn_bwd(const void* q, int64_t q_sb, int64_t q_ss, const voi
   {
     float* part = delta + 2 * B * H * S;
     const int64_t nkb = cdiv64(S, DKV2_KEYS);
-    static const int dkv_variant = getenv("LLX_ATTN_DKV") ? atoi(getenv("LLX_ATTN_DKV")) : 3;
-    if (dkv_variant == 2) {
-      if (a.flags) hipLaunchKernelGGL(attn_bwd_dkv2_kernel<true>, dim3((unsigned)(nkb * B * H)), dim3(256), DKV_LDS_BYTES, stream, a, part);
-      else hipLaunchKernelGGL(attn_bwd_dkv2_kernel<false>, dim3((unsigned)(nkb * B * H)), dim3(256), DKV_LDS_BYTES, stream, a, part);
-    } else {
-      if (g_bwd_stamps && !a.flags) {
-        a.stamps = g_bwd_stamps;
-        (void)hipFuncSetAttribute((const void*)attn_bwd_dkv3_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV3_LDS_BYTES);
-        hipLaunchKernelGGL((attn_bwd_dkv3_kernel<false, true>), dim3((unsigned)(nkb * B * H)), dim3(256), DKV3_LDS_BYTES, stream, a, part);
-      } else if (a.flags) hipLaunchKernelGGL(attn_bwd_dkv3_kernel<true>, dim3((unsigned)(nkb * B * H)), dim3(256), DKV3_LDS_BYTES, stream, a, part);
-      else hipLaunchKernelGGL(attn_bwd_dkv3_kernel<false>, dim3((unsigned)(nkb * B * H)), dim3(256), DKV3_LDS_BYTES, stream, a, part);
-    }
-    LLX_LAUNCH_CHECK("llx_attn_bwd(dkv2)");
+    if (g_bwd_stamps && !a.flags) {
+      a.stamps = g_bwd_stamps;
+      (void)hipFuncSetAttribute((const void*)attn_bwd_dkv3_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV3_LDS_BYTES);
+      hipLaunchKernelGGL((attn_bwd_dkv3_kernel<false, true>), dim3((unsigned)(nkb * B * H)), dim3(256), DKV3_LDS_BYTES, stream, a, part);
+    } else if (a.flags) hipLaunchKernelGGL(attn_bwd_dkv3_kernel<true>, dim3((unsigned)(nkb * B * H)), dim3(256), DKV3_LDS_BYTES, stream, a, part);
+    else hipLaunchKernelGGL(attn_bwd_dkv3_kernel<false>, dim3((unsigned)(nkb * B * H)), dim3(256), DKV3_LDS_BYTES, stream, a, part);
+    LLX_LAUNCH_CHECK("llx_attn_bwd(dkv)");
     const int64_t plane = B * S * KVH * HD;
     hipLaunchKernelGGL(attn_dkv_reduce_kernel, dim3((unsigned)cdiv64(plane / 8, 256)), dim3(256), 0, stream, a, (const float*)part);
     LLX_LAUNCH_CHECK("llx_attn_bwd(dkv reduce)");
