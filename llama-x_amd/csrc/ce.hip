@@ -16,7 +16,8 @@ __global__ void ce_count_kernel(const int64_t* __restrict__ labels, float* __res
 
 // One block per row.  row_loss[t] = lse - x[label] (0 for ignored rows).
 // dlogits (nullable, may alias logits) = (softmax - onehot) * inv_count[0]   (zero row when ignored).
-__global__ __launch_bounds__(CE_THREADS) void ce_row_kernel(const bf16_t* __restrict__ logits, bf16_t* __restrict__ dlogits, int64_t ld,
+// logits / dlogits carry no __restrict__: the caller passes the same buffer for both (in-place gradient).
+__global__ __launch_bounds__(CE_THREADS) void ce_row_kernel(const bf16_t* logits, bf16_t* dlogits, int64_t ld,
                                                              int64_t dld, const int64_t* __restrict__ labels, float* __restrict__ row_loss,
                                                              const float* __restrict__ inv_count, int V) {
   __shared__ float red[16];
@@ -33,6 +34,8 @@ __global__ __launch_bounds__(CE_THREADS) void ce_row_kernel(const bf16_t* __rest
     }
     return;
   }
+  // the label's logit is read BEFORE anything is written: pass 2 of another wave overwrites it in place when dlogits == logits
+  const float xl = (label >= 0 && label < V) ? bf2f(x[label]) : 0.f;
   // pass 1: online (max, sum exp)
   float m = -INFINITY, s = 0.f;
   for (int c = threadIdx.x; c < nchunk; c += CE_THREADS) {
@@ -53,10 +56,7 @@ __global__ __launch_bounds__(CE_THREADS) void ce_row_kernel(const bf16_t* __rest
   const float gm = block_max(m, red);
   s = block_sum(s * __expf(m - gm), red);
   const float lse = gm + __logf(s);
-  if (threadIdx.x == 0) {
-    const float xl = (label >= 0 && label < V) ? bf2f(x[label]) : 0.f;
-    row_loss[t] = lse - xl;
-  }
+  if (threadIdx.x == 0) row_loss[t] = lse - xl;
   if (!dlogits) return;
   const float gs = inv_count[0];
   bf16_t* dx = dlogits + t * dld;

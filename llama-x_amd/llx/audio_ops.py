@@ -15,6 +15,7 @@ from torch import Tensor, nn
 
 from . import _lib as L
 from . import kernels as K
+from .ops import _load, _save
 
 BF16 = torch.bfloat16
 
@@ -144,16 +145,14 @@ class AudioPrefixFn(torch.autograd.Function):
             K.gemm_nt(A2, w2r, out=z2[b], epilogue=K.EPI_BIAS, e=b2.detach())
             _gelu_fwd(z2[b], x[b, :L2])
         K.embedding_fwd(tokens, emb.detach(), out=x[:, L2:])
-        ctx.save_for_backward(tokens)
-        ctx.saved = (feat_pad, z1, z2, h1, w1r, w2r, emb.shape[0])
-        ctx.dims = (B, L1, L2, C, D)
+        _save(ctx, tokens, feat_pad, z1, z2, h1, w1r, w2r)
+        ctx.dims = (B, L1, L2, C, D, emb.shape[0])
         return x
 
     @staticmethod
     def backward(ctx, dx: Tensor):
-        (tokens,) = ctx.saved_tensors
-        feat_pad, z1, z2, h1, w1r, w2r, vocab = ctx.saved
-        B, L1, L2, C, D = ctx.dims
+        tokens, feat_pad, z1, z2, h1, w1r, w2r = _load(ctx)
+        B, L1, L2, C, D, vocab = ctx.dims
         dx = dx.contiguous()
         need_emb, need_w1, need_b1, need_w2, need_b2 = ctx.needs_input_grad[2:]
         demb = K.embedding_bwd(tokens, dx[:, L2:], vocab).to(BF16) if need_emb else None

@@ -4,6 +4,8 @@ of SURVEY 8a).  Pure host code: index / label / mask tensors are bit-exact with 
   pad_batch            <- _data_iter_padding batch body          (train_metamathqa.py:38-46)
   pack_documents       <- _data_iter_document_mask                (train_metamathqa.py:51-83), yields doc_ids for MaskSpec
   prepare_audio_batch  <- LibriSpeech._prepare_batch              (train_librispeech.py:68-86)
+  librispeech_samples  <- LibriSpeech.__init__ transcript listing (train_librispeech.py:53-66)
+  UtterancePacker      <- LibriSpeech.__iter__                    (train_librispeech.py:88-124)
   LRScheduler          <- train_utils.py:38-66
 """
 from __future__ import annotations
@@ -86,6 +88,67 @@ def prepare_audio_batch(batch: Sequence[tuple[Tensor, list[int]]], audio_length:
     tokens = torch.tensor([list(t) + [pad_id] * (width - len(t)) for t in toks])
     labels = torch.tensor([list(t[1:]) + [-100] * (width - len(t) + 1) for t in toks])
     return audio, tokens, labels
+
+
+def librispeech_samples(data_dir, tokenize) -> list[tuple[str, list[int]]]:
+    """(audio path relative to data_dir, token ids of " <lower-cased transcript>.") per transcript FILE, sorted.
+
+    The reference's loop body after ``for line in open(file)`` is de-indented (train_librispeech.py:55-61), so only the LAST line
+    of every ``*.trans.txt`` becomes a sample.  Kept as is: a drop-in must hand the model the same sample list."""
+    from pathlib import Path
+
+    root = Path(data_dir)
+    out = []
+    for trans in root.glob("**/*.trans.txt"):
+        rows = [ln.rstrip().split(" ", 1) for ln in open(trans)]
+        if not rows:
+            continue
+        stem, text = rows[-1]
+        out.append((str((trans.parent / f"{stem}.flac").relative_to(root)), tokenize(f" {text.lower()}.")))
+    out.sort()
+    return out
+
+
+class UtterancePacker:
+    """Endless iterator of (audio fp32 [B, duration*sr], tokens int64 [B, St], labels int64 [B, St]) host batches: utterances in
+    shuffled order are concatenated until the next one would exceed ``audio_duration`` seconds; a pack's tokens are
+    ``[bos] + utterance tokens... + [eos]``; clips longer than ``audio_duration`` are dropped; ``batch_size`` closed packs make a
+    batch (zero-padded audio, ``pad_id`` / -100 padded tokens / labels through :func:`prepare_audio_batch`).
+
+    ``load_audio(relative_path) -> (waveform [channels, n], sample_rate)`` is injected: the reference calls ``torchaudio.load``
+    (train_librispeech.py:101), which this image does not have.  Feed it to :class:`DevicePrefetcher` for pinned, overlapped H2D."""
+
+    def __init__(self, samples: Sequence[tuple[str, list[int]]], load_audio, *, audio_duration: float, seq_len_multiple: int, batch_size: int,
+                 bos_id: int, eos_id: int, pad_id: int, sample_rate: int = 16_000, generator=None):
+        self.samples, self.load_audio = list(samples), load_audio
+        self.limit, self.sr, self.mult, self.bs = audio_duration, sample_rate, seq_len_multiple, batch_size
+        self.bos, self.eos, self.pad = bos_id, eos_id, pad_id
+        self.generator = generator
+
+    def __iter__(self):
+        closed: list[tuple[Tensor, list[int]]] = []
+        clips: list[Tensor] = []
+        toks: list[int] = [self.bos]
+        secs = 0
+        n_pad = int(self.limit * self.sr)
+        while True:
+            for i in torch.randperm(len(self.samples), generator=self.generator).tolist():
+                path, utt_tokens = self.samples[i]
+                wav, fs = self.load_audio(path)
+                assert fs == self.sr, (fs, self.sr)
+                mono = wav.mean(0)
+                dur = mono.shape[0] / fs
+                if dur > self.limit:
+                    continue  # over-long clip: skipped, the open pack is left untouched
+                if secs + dur > self.limit:  # close the open pack; this clip opens the next one
+                    closed.append((torch.cat(clips, dim=0), toks + [self.eos]))
+                    clips, toks, secs = [], [self.bos], 0
+                    if len(closed) == self.bs:
+                        yield prepare_audio_batch(closed, n_pad, self.mult, self.pad)
+                        closed = []
+                clips.append(mono)
+                toks = toks + list(utt_tokens)
+                secs += dur
 
 
 class LRScheduler:

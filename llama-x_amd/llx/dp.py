@@ -26,7 +26,7 @@ class GradBuckets:
         self._params = params
         if not self.active:
             # single replica: nothing to exchange - leave .grad to autograd (no flat views, no accumulate-add kernels)
-            self.buckets, self._handles, self._hooks, self.sync_enabled = [], [], [], True
+            self.buckets, self._handles, self._hooks, self.sync_enabled, self.hook_launches = [], [], [], True, 0
             return
         # backward produces gradients roughly in reverse registration order: bucket 0 = last layers
         params = list(reversed(params))
@@ -44,6 +44,7 @@ class GradBuckets:
             self.buckets.append(self._make(cur))
         self._handles = []
         self._hooks = []
+        self.hook_launches = 0  # all-reduces started from backward hooks (i.e. overlapped with the rest of backward)
         if overlap:
             for bi, b in enumerate(self.buckets):
                 for p in b["params"]:
@@ -62,9 +63,12 @@ class GradBuckets:
 
     def _make_hook(self, bi: int):
         def hook(param):
+            if not self.sync_enabled:
+                return  # non-final micro-batch of an accumulation: gradients keep summing into the flat buffer, nothing is counted
             b = self.buckets[bi]
             b["pending"] -= 1
-            if b["pending"] == 0 and self.sync_enabled and not (b["flat"].is_cuda and torch.cuda.is_current_stream_capturing()):
+            if b["pending"] == 0 and not (b["flat"].is_cuda and torch.cuda.is_current_stream_capturing()):
+                self.hook_launches += 1
                 self._launch(b)
 
         return hook

@@ -369,6 +369,38 @@ class GroupPlan:
         return dx, grads
 
 
+def _save(ctx, *objs) -> None:
+    """Route EVERY tensor a backward needs through ``save_for_backward`` (nested tuples / lists / None allowed): saved-tensor hooks
+    (non-reentrant ``checkpoint`` at modelling/llama.py, CPU offload) then see the activations and can drop / recompute them,
+    and autograd's in-place version checks cover them.  Only the nesting structure stays on ``ctx``."""
+    flat: list[Tensor] = []
+
+    def enc(o):
+        if isinstance(o, Tensor):
+            flat.append(o)
+            return ("t", len(flat) - 1)
+        if isinstance(o, (tuple, list)):
+            return ("l", [enc(x) for x in o])
+        return ("c", o)
+
+    ctx._llx_spec = [enc(o) for o in objs]
+    ctx.save_for_backward(*flat)
+
+
+def _load(ctx) -> list:
+    flat = ctx.saved_tensors
+
+    def dec(sp):
+        kind, v = sp
+        if kind == "t":
+            return flat[v]
+        if kind == "l":
+            return tuple(dec(x) for x in v)
+        return v
+
+    return [dec(sp) for sp in ctx._llx_spec]
+
+
 def _plans_tensors(plans: Sequence[LinearPlan]) -> tuple[list[Tensor], list[int]]:
     ts, counts = [], []
     for p in plans:
@@ -387,8 +419,8 @@ class LinearFn(Function):
         K.L.require_cuda(x)
         x2 = K._rows2d(x)
         y, t = plan.forward(x2)
-        ctx.plan, ctx.t = plan, t
-        ctx.x2 = x2
+        ctx.plan = plan
+        _save(ctx, x2, t)
         ctx.xshape = x.shape
         return y.view(*x.shape[:-1], plan.N)
 
@@ -397,7 +429,8 @@ class LinearFn(Function):
         plan: LinearPlan = ctx.plan
         dy2 = K._rows2d(dy)
         needs = ctx.needs_input_grad[2:]
-        dx, grads = plan.backward(dy2, ctx.x2, ctx.t, needs, need_dx=ctx.needs_input_grad[0])
+        x2, t = _load(ctx)
+        dx, grads = plan.backward(dy2, x2, t, needs, need_dx=ctx.needs_input_grad[0])
         return (dx.view(ctx.xshape) if dx is not None else None, None, *grads)
 
 
@@ -429,14 +462,13 @@ class RMSNormFn(Function):
     @staticmethod
     def forward(ctx, x: Tensor, w: Tensor, eps: float):
         y, rstd = K.rmsnorm_fwd(x.contiguous(), w.detach(), eps)
-        ctx.save_for_backward(x, w)
-        ctx.rstd = rstd
+        ctx.save_for_backward(x, w, rstd)
         return y
 
     @staticmethod
     def backward(ctx, dy: Tensor):
-        x, w = ctx.saved_tensors
-        dx, dw = K.rmsnorm_bwd(dy.contiguous(), x.contiguous(), w.detach(), ctx.rstd, ctx.needs_input_grad[1])
+        x, w, rstd = ctx.saved_tensors
+        dx, dw = K.rmsnorm_bwd(dy.contiguous(), x.contiguous(), w.detach(), rstd, ctx.needs_input_grad[1])
         return dx, dw, None
 
 
@@ -480,15 +512,16 @@ class AttnBlockFn(Function):
         o2 = o.view(B * S, H * hd)
         y, to = meta.wo.forward(o2, None, x2 if meta.fuse_residual else None)
         ctx.meta = meta
-        ctx.save_for_backward(x, rope, norm_w)
-        ctx.saved = (x2, xn, rstd, qkv3, o, lse, tqkv, to)
+        # x2 is x itself (or its contiguous copy) and xn == x2 without the fused norm: saved once, by identity, below
+        _save(ctx, x, rope, norm_w, x2, xn if meta.fuse_norm else None, rstd, qkv3, o, lse, tqkv, to)
         return y.view(B, S, D)
 
     @staticmethod
     def backward(ctx, dy: Tensor):
         meta: AttnBlockMeta = ctx.meta
-        x, rope, norm_w = ctx.saved_tensors
-        x2, xn, rstd, qkv3, o, lse, tqkv, to = ctx.saved
+        x, rope, norm_w, x2, xn, rstd, qkv3, o, lse, tqkv, to = _load(ctx)
+        if xn is None:
+            xn = x2
         B, S, D = x.shape
         H, KVH, hd = meta.H, meta.KVH, meta.hd
         dy2 = K._rows2d(dy.contiguous())
@@ -560,15 +593,15 @@ class MLPBlockFn(Function):
             h = K.swiglu_fwd(gu[:, :I], gu[:, I:])
         y, t2 = meta.w2.forward(h, None, x2 if meta.fuse_residual else None)
         ctx.meta = meta
-        ctx.save_for_backward(x, norm_w)
-        ctx.saved = (x2, xn, rstd, gu, h, t13, t2)
+        _save(ctx, x, norm_w, x2, xn if meta.fuse_norm else None, rstd, gu, h, t13, t2)
         return y.view(shape)
 
     @staticmethod
     def backward(ctx, dy: Tensor):
         meta: MLPBlockMeta = ctx.meta
-        x, norm_w = ctx.saved_tensors
-        x2, xn, rstd, gu, h, t13, t2 = ctx.saved
+        x, norm_w, x2, xn, rstd, gu, h, t13, t2 = _load(ctx)
+        if xn is None:
+            xn = x2
         T, I = x2.shape[0], meta.w13.Ns[0]
         dy2 = K._rows2d(dy.contiguous())
         needs = list(ctx.needs_input_grad[3:])
@@ -608,15 +641,13 @@ class HeadLossFn(Function):
         need_grad = any(ctx.needs_input_grad)
         loss, dlogits = K.ce_fwd_bwd(logits, labels, write_grad=need_grad)
         ctx.plan, ctx.eps = plan, eps
-        ctx.save_for_backward(x, norm_w)
-        ctx.saved = (x2, xn, rstd, dlogits, t)
+        _save(ctx, x, norm_w, x2, xn, rstd, dlogits, t)
         return loss
 
     @staticmethod
     def backward(ctx, gout: Tensor):
         plan: LinearPlan = ctx.plan
-        x, norm_w = ctx.saved_tensors
-        x2, xn, rstd, dlogits, t = ctx.saved
+        x, norm_w, x2, xn, rstd, dlogits, t = _load(ctx)
         needs = ctx.needs_input_grad[5:]
         g32 = gout.detach().to(torch.float32).reshape(1)
         dxn, grads = plan.backward(dlogits, xn, t, needs, need_dx=ctx.needs_input_grad[0] or ctx.needs_input_grad[1])

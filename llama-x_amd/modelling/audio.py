@@ -1,6 +1,7 @@
 """Early-fusion audio + text Llama (API of /root/reference/modelling/audio.py:12-101) on gfx950 kernels.
 
-Front end: log-mel spectrogram (framed real DFT as an MFMA GEMM + mel filterbank, csrc/mel.hip) -> CMN ->
+Front end: log-mel spectrogram (framed, windowed 512-point real DFT evaluated directly in fp32 on the VALU, |.|^2 and the
+slaney mel filterbank in the same kernel: csrc/audio.hip `mel_power_kernel`) -> log10 / clip / CMN (`logmel_cmn_kernel`) ->
 Conv1d(k3,s1)+GELU -> Conv1d(k3,s2)+GELU as implicit GEMMs over a time-major, zero-padded activation buffer
 (the im2col matrix of a k=3 convolution is a strided VIEW of that buffer) with bias+GELU fused in the GEMM epilogue.
 The second convolution writes straight into the [audio ; text] sequence buffer, so torch.cat (audio.py:63) never runs.

@@ -540,6 +540,56 @@ def prepare_audio_batch(batch: Sequence[tuple[Tensor, list[int]]], audio_length:
     return audio, torch.tensor(tokens), torch.tensor(labels)
 
 
+def list_transcripts(trans_files: Sequence[tuple[str, str, Sequence[str]]], tokenize) -> list[tuple[str, list[int]]]:
+    """LibriSpeech.__init__ sample listing (train_librispeech.py:53-63), over an in-memory stand-in of the
+    ``**/*.trans.txt`` glob: ``trans_files`` = (directory relative to data_dir, file name, lines).  Reproduces the reference's
+    de-indented body (:58-61): the three statements after the inner ``for line`` loop run ONCE per transcript file, with the
+    variables of its LAST line, so each file contributes exactly one sample.  Sorted as :63."""
+    samples = []
+    for rel_dir, _fname, lines in trans_files:
+        for line in lines:
+            audio_fname, text = line.rstrip().split(" ", 1)
+        audio_path = f"{rel_dir}/{audio_fname}.flac" if rel_dir else f"{audio_fname}.flac"
+        samples.append((audio_path, tokenize(f" {text.lower()}.")))
+    samples.sort()
+    return samples
+
+
+def pack_utterances(samples: Sequence[tuple[str, list[int]]], load_audio, order: Iterable[int], *, audio_duration: float,
+                    sample_rate: int, batch_size: int, seq_len_multiple: int, bos_id: int, eos_id: int, pad_id: int,
+                    state: Optional[dict] = None) -> Iterator[tuple[Tensor, Tensor, Tensor]]:
+    """LibriSpeech.__iter__ (train_librispeech.py:88-124) over ONE pass of ``order`` (the caller owns the
+    ``torch.randperm`` / endless ``while True`` of :95-98; ``state`` carries batch/audio/tokens/duration across passes).
+    ``load_audio(path) -> (waveform [channels, n], fs)`` stands in for ``torchaudio.load`` (:101).  Utterances are averaged
+    over channels (:103), clips longer than ``audio_duration`` are skipped (:106-108); when the next clip would overflow the
+    packed duration the pack is closed with eos (:110-112), appended to the batch, and a full batch is emitted through
+    _prepare_batch (:114-116); the overflowing clip then opens the next pack (:118-124)."""
+    st = state if state is not None else {}
+    if "tokens" not in st:
+        st.update(batch=[], audio=[], tokens=[bos_id], duration=0)
+    for idx in order:
+        this_audio_path, this_tokens = samples[int(idx)]
+        this_audio, fs = load_audio(this_audio_path)
+        assert fs == sample_rate
+        this_audio = this_audio.mean(0)
+        this_duration = this_audio.shape[0] / fs
+        if this_duration > audio_duration:
+            continue
+        if st["duration"] + this_duration > audio_duration:
+            audio = torch.cat(st["audio"], dim=0)
+            st["tokens"].append(eos_id)
+            st["batch"].append((audio, st["tokens"]))
+            if len(st["batch"]) == batch_size:
+                yield prepare_audio_batch(st["batch"], int(audio_duration * sample_rate), seq_len_multiple, pad_id)
+                st["batch"] = []
+            st["audio"] = []
+            st["tokens"] = [bos_id]
+            st["duration"] = 0
+        st["audio"].append(this_audio)
+        st["tokens"].extend(this_tokens)
+        st["duration"] += this_duration
+
+
 def lr_at(step: int, lr: float, n_steps: int, warmup: float, decay: float) -> float:
     """LRScheduler.get_lr (train_utils.py:38-58): trapezoid."""
     t1, t2, t3 = int(n_steps * warmup), int(n_steps * (1 - decay)), n_steps

@@ -65,6 +65,25 @@ def _worker(rank, world, port, q):
     ref_model.zero_grad()
     (ref_model(data).sum() / world).backward()
     ok3 = all(torch.allclose(p.grad, dict(ref_model.named_parameters())[n].grad, atol=1e-6) for n, p in m2.named_parameters() if p.requires_grad)
+    # step 4: Trainer.step with grad_accum=2 and NO finish() between the micro-batches (llx/train.py): the hooks must stay armed
+    # through the first micro-batch and launch EVERY bucket's all-reduce from inside the last backward (overlap kept).
+    from llx.train import Trainer
+
+    m3 = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.Tanh(), torch.nn.Linear(16, 4), torch.nn.Linear(4, 1))
+    m3.load_state_dict(model.state_dict())
+    opt = torch.optim.SGD([p for p in m3.parameters()], lr=0.0)
+    tr = Trainer(m3, opt, grad_accum=2, n_buckets=2)
+    seen = {}
+    opt.register_step_pre_hook(lambda o, a, k: seen.update({n: p.grad.clone() for n, p in m3.named_parameters()}))
+    for _ in range(2):  # two optimizer steps: the counters must re-arm after finish()
+        before = tr.buckets.hook_launches
+        tr.step([lambda m: m(x).sum(), lambda m: m(x).sum()])
+        launched = tr.buckets.hook_launches - before
+        ref_model.zero_grad()
+        (ref_model(data).sum() / world).backward()  # 2 micro-batches of loss/2 each == one batch
+        ok4 = launched == len(tr.buckets.buckets) and all(
+            torch.allclose(seen[n], dict(ref_model.named_parameters())[n].grad, atol=1e-5) for n in seen)
+        ok3 = ok3 and ok4
     q.put((rank, bool(ok), bool(ok2 and ok3), float(local_only.abs().sum())))
     dist.destroy_process_group()
 

@@ -71,6 +71,67 @@ def test_prepare_audio_batch():
     assert labels.tolist() == [[7, 8, 2, -100, -100, -100, -100, -100], [9, 2, 4, 4, 2, -100, -100, -100]]
 
 
+# ---------------------------------------------------------------------------------------------- N3 LibriSpeech utterance packer
+def _clips():
+    """Synthetic utterances at 10 Hz 'sample rate': name -> (waveform [channels, n], fs); durations 0.5 / 0.4 / 1.2 / 0.3 / 0.6 s."""
+    wav = lambda n, v, ch=1: torch.full((ch, n), float(v))  # noqa: E731
+    return {"a.flac": (wav(5, 1), 10), "b.flac": (wav(4, 2, ch=2), 10), "c.flac": (wav(12, 3), 10), "d.flac": (wav(3, 4), 10),
+            "e.flac": (wav(6, 5), 10)}
+
+
+def test_utterance_packer_hand_case():
+    """train_librispeech.py:88-124 on a hand-computed case: limit 1.0 s, batch of 2 packs, seq multiple 4, bos 1 / eos 2 / pad 0."""
+    clips = _clips()
+    samples = [("a.flac", [10, 11]), ("b.flac", [20]), ("c.flac", [30, 31]), ("d.flac", [40, 41, 42]), ("e.flac", [50])]
+    kw = dict(audio_duration=1.0, sample_rate=10, batch_size=2, seq_len_multiple=4, bos_id=1, eos_id=2, pad_id=0)
+    st = {}
+    out = list(O.pack_utterances(samples, clips.__getitem__, [0, 1, 2, 3, 4, 0], state=st, **kw))
+    # a (0.5) + b (0.4) = 0.9; c (1.2 s) is over-long: skipped; d (0.3) would make 1.2 > 1.0 -> pack {a,b} closes, d opens;
+    # e (0.6): 0.3 + 0.6 = 0.9 fits; a again (0.5): 0.9 + 0.5 > 1.0 -> pack {d,e} closes -> batch of 2 emitted; a opens the next pack
+    assert len(out) == 1
+    audio, tokens, labels = out[0]
+    assert audio.shape == (2, 10) and audio.dtype is torch.float32
+    assert audio[0].tolist() == [1, 1, 1, 1, 1, 2, 2, 2, 2, 0]      # b is stereo: channel mean; zero padded to 1.0 s
+    assert audio[1].tolist() == [4, 4, 4, 5, 5, 5, 5, 5, 5, 0]
+    assert tokens.tolist() == [[1, 10, 11, 20, 2, 0, 0, 0], [1, 40, 41, 42, 50, 2, 0, 0]]
+    assert labels.tolist() == [[10, 11, 20, 2, -100, -100, -100, -100], [40, 41, 42, 50, 2, -100, -100, -100]]
+    assert st["tokens"] == [1, 10, 11] and st["duration"] == 0.5 and st["batch"] == [], "the overflowing clip opens the next pack"
+
+
+def test_utterance_packer_product_matches_oracle(tmp_path):
+    from llx import data as D
+
+    clips = _clips()
+    gen = torch.Generator().manual_seed(7)
+    lens = torch.randint(2, 9, (40,), generator=gen).tolist()
+    big = {f"u{i:02d}.flac": (torch.rand(1 + i % 2, n, generator=gen), 10) for i, n in enumerate(lens)}
+    big["long.flac"] = (torch.rand(1, 15, generator=gen), 10)
+    samples = [(k, [100 + i, 200 + i][: 1 + i % 2]) for i, k in enumerate(sorted(big))]
+    kw = dict(audio_duration=1.0, batch_size=3, seq_len_multiple=4, bos_id=1, eos_id=2, pad_id=0)
+    g1 = torch.Generator().manual_seed(3)
+    it = iter(D.UtterancePacker(samples, big.__getitem__, sample_rate=10, generator=g1, **kw))
+    got = [next(it) for _ in range(7)]  # spans more than one shuffled pass
+    g2 = torch.Generator().manual_seed(3)
+    want, st = [], {}
+    while len(want) < 7:
+        want += list(O.pack_utterances(samples, big.__getitem__, torch.randperm(len(samples), generator=g2), sample_rate=10, state=st, **kw))
+    for a, b in zip(got, want):
+        assert all(torch.equal(u, v) for u, v in zip(a, b))
+    # transcript listing incl. the reference's de-indentation quirk (:55-61): one sample per *.trans.txt, from its LAST line
+    d = tmp_path / "libri" / "84" / "121123"
+    d.mkdir(parents=True)
+    (d / "84-121123.trans.txt").write_text("84-121123-0000 GO DO YOU HEAR\n84-121123-0001 BUT IN LESS THAN FIVE\n")
+    d2 = tmp_path / "libri" / "19" / "198"
+    d2.mkdir(parents=True)
+    (d2 / "19-198.trans.txt").write_text("19-198-0000 NORTHANGER ABBEY\n")
+    tok = lambda s: [ord(c) for c in s]  # noqa: E731
+    got_s = D.librispeech_samples(tmp_path / "libri", tok)
+    want_s = O.list_transcripts([("84/121123", "84-121123.trans.txt", ["84-121123-0000 GO DO YOU HEAR\n", "84-121123-0001 BUT IN LESS THAN FIVE\n"]),
+                                 ("19/198", "19-198.trans.txt", ["19-198-0000 NORTHANGER ABBEY\n"])], tok)
+    assert got_s == want_s == [("19/198/19-198-0000.flac", tok(" northanger abbey.")), ("84/121123/84-121123-0001.flac", tok(" but in less than five."))]
+    assert clips  # (fixture reused above)
+
+
 def test_lr_schedule():
     f = lambda s: O.lr_at(s, 1.0, 100, 0.1, 0.2)  # noqa: E731
     assert f(0) == 0.0 and f(5) == 0.5 and f(10) == 1.0 and f(79) == 1.0 and f(80) == 1.0 and f(90) == 0.5 and f(100) == 1.0
