@@ -143,6 +143,19 @@ int llx_lora_group_pack(const void* const* lora_a, const void* const* lora_b, co
 int llx_lora_pack(const void* in, int64_t ld, void* out, int64_t out_ld, int64_t R, int64_t C, int64_t row_off, int64_t col_off, float scale,
                   int transpose, llx_stream_t s);   /* batched LoRA operand images of a linear group (q|k|v, gate|up) */
 
+/* ---- DoRA (modelling/lora.py:47-62): out = (x W^T + s x A^T B^T) * m / ||W + s B A||_row (+ bias).  The row norm is evaluated from
+ *      ||W_n||^2 (llx_rownorm2, cached per frozen weight), G = W A^T and A A^T (llx_skinny_nt) - no dense [out,in] temporary;
+ *      llx_dora_colscale -> c = m / norm (bf16, the column scale: llx_scale / llx_colscale_bias / GEMM epilogue 4) and 1/norm (fp32);
+ *      llx_colsum_mul -> d m[n] = (sum_rows dy * z)[n] / norm[n], two deterministic stages. --------------------------------- */
+int llx_rownorm2(const void* W, int64_t ld, float* out, int64_t rows, int64_t cols, llx_stream_t s);
+int llx_dora_colscale(const float* wn2, const void* G /*bf16 [N,64]*/, const void* b2 /*bf16 [N,64] = s*B*/, const void* AAt /*bf16 [R,64]*/,
+                      const void* m /*bf16 [N]*/, void* c /*bf16 [N]*/, float* inv_norm /*fp32 [N]*/, int64_t N, int64_t R, llx_stream_t s);
+int64_t llx_colsum_mul_workspace_bytes(int64_t N);
+int llx_colsum_mul(const void* a, int64_t lda, const void* b, int64_t ldb, const float* colscale /*nullable fp32 [N]*/, void* out /*bf16 [N]*/,
+                   void* workspace, int64_t M, int64_t N, llx_stream_t s);
+int llx_colscale_bias(const void* x, int64_t x_ld, void* y, int64_t y_ld, const void* colscale /*bf16 [cols]*/, const void* bias /*nullable*/,
+                      int64_t rows, int64_t cols, llx_stream_t s);
+
 /* ---- audio front end (modelling/audio.py:26-36,53-60): MelSpectrogram(n_fft 512, win 400, hop 160, 128 slaney mels,
  *      power 2, centre/reflect) -> log10/clip/CMN -> bf16 time-major padded features; exact-erf GELU; conv k=3 helpers.
  *      twiddle fp32 [512][2], window fp32 [512], fbank fp32 [257][n_mels] are host-built constants. --------------- */

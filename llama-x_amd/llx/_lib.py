@@ -56,6 +56,11 @@ SIGNATURES: dict[str, tuple] = {
     "llx_lora_group_pack": (c_int, [_P, _P, _P, _P, _I, _L, _F, _P, _P, _P, _P, _P]),
     "llx_lora_pack": (c_int, [_P, _L, _P, _L, _L, _L, _L, _L, _F, _I, _P]),
     "llx_pad64": (c_int, [_P, _L, _P, _L, _L, _F, _I, _P]),
+    "llx_rownorm2": (c_int, [_P, _L, _P, _L, _L, _P]),
+    "llx_dora_colscale": (c_int, [_P, _P, _P, _P, _P, _P, _P, _L, _L, _P]),
+    "llx_colsum_mul_workspace_bytes": (c_int64, [_L]),
+    "llx_colsum_mul": (c_int, [_P, _L, _P, _L, _P, _P, _P, _L, _L, _P]),
+    "llx_colscale_bias": (c_int, [_P, _L, _P, _L, _P, _P, _L, _L, _P]),
     "llx_ce_workspace_bytes": (c_int64, [_L]),
     "llx_ce_fwd_bwd": (c_int, [_P, _L, _P, _L, _P, _P, _P, _L, _L, _P]),
     "llx_skinny_nt": (c_int, [_P, _L, _P, _L, _P, _L, _L, _L, _P, _P]),

@@ -246,6 +246,56 @@ def colsum(dy: Tensor) -> Tensor:
     return out.view(N)
 
 
+# ------------------------------------------------------------------------------------------------- DoRA
+def rownorm2(w: Tensor) -> Tensor:
+    """fp32 [N]: squared L2 norm of every row of the bf16 matrix w [N, K]."""
+    _chk_bf16(w)
+    assert w.dim() == 2 and w.stride(1) == 1
+    out = torch.empty(w.shape[0], device=w.device, dtype=torch.float32)
+    L.check(_lib().llx_rownorm2(L.ptr(w), w.stride(0), L.ptr(out), w.shape[0], w.shape[1], L.stream()), "llx_rownorm2")
+    return out
+
+
+def dora_colscale(wn2: Tensor, G: Tensor, b2: Tensor, AAt: Tensor, m: Tensor, c: Tensor, inv_norm: Tensor, R: int) -> None:
+    """c[n] = m[n] / ||W_n + s B_n A|| (bf16), inv_norm[n] = 1 / norm (fp32) for the N rows these views cover (DoRA, lora.py:55-59)."""
+    _chk_bf16(G, b2, AAt, m, c)
+    N = m.shape[0]
+    assert wn2.dtype is torch.float32 and inv_norm.dtype is torch.float32 and wn2.shape == (N,) and inv_norm.shape == (N,) and c.shape == (N,)
+    assert G.shape == (N, SK_PAD) and b2.shape == (N, SK_PAD) and AAt.shape[1] == SK_PAD and AAt.shape[0] >= R
+    for t in (wn2, G, b2, AAt, m, c, inv_norm):
+        assert t.is_contiguous()
+    L.check(_lib().llx_dora_colscale(L.ptr(wn2), L.ptr(G), L.ptr(b2), L.ptr(AAt), L.ptr(m), L.ptr(c), L.ptr(inv_norm), N, R, L.stream()),
+            "llx_dora_colscale")
+
+
+def colsum_mul(a: Tensor, b: Tensor, colscale: Optional[Tensor] = None) -> Tensor:
+    """bf16 [N]: colscale[n] * sum_m a[m, n] * b[m, n] (fp32 accumulate, deterministic)."""
+    _chk_bf16(a, b)
+    assert a.shape == b.shape and a.dim() == 2 and a.stride(1) == 1 and b.stride(1) == 1
+    M, N = a.shape
+    if colscale is not None:
+        assert colscale.dtype is torch.float32 and colscale.shape == (N,) and colscale.is_contiguous()
+    out = torch.empty(N, device=a.device, dtype=BF16)
+    ws = torch.empty(_lib().llx_colsum_mul_workspace_bytes(N), device=a.device, dtype=torch.uint8)
+    L.check(_lib().llx_colsum_mul(L.ptr(a), a.stride(0), L.ptr(b), b.stride(0), L.ptr(colscale), L.ptr(out), L.ptr(ws), M, N, L.stream()),
+            "llx_colsum_mul")
+    return out
+
+
+def colscale_bias(x: Tensor, colscale: Tensor, bias: Optional[Tensor] = None, out: Optional[Tensor] = None) -> Tensor:
+    """bf16(bf16(x * colscale[n]) + bias[n]) on [M, N] rows (the two roundings of DoRALinear's rescale and bias add)."""
+    _chk_bf16(x, colscale, bias, out)
+    assert x.dim() == 2 and x.stride(1) == 1 and colscale.shape == (x.shape[1],) and colscale.is_contiguous()
+    if bias is not None:
+        assert bias.shape == (x.shape[1],) and bias.is_contiguous()
+    if out is None:
+        out = torch.empty(x.shape, device=x.device, dtype=BF16)
+    assert out.shape == x.shape and out.stride(1) == 1
+    L.check(_lib().llx_colscale_bias(L.ptr(x), x.stride(0), L.ptr(out), out.stride(0), L.ptr(colscale), L.ptr(bias), x.shape[0], x.shape[1],
+                                     L.stream()), "llx_colscale_bias")
+    return out
+
+
 # ------------------------------------------------------------------------------------------------- embedding
 def embedding_fwd(ids: Tensor, table: Tensor, out: Optional[Tensor] = None) -> Tensor:
     """out[b, s, :] = table[ids[b, s], :]; ``out`` may be a strided [B, S, D] view (e.g. behind an audio prefix)."""

@@ -67,11 +67,12 @@ class LinearPlan:
         self.lora_a = getattr(m, "lora_a", None) if self.rank > 0 else None
         self.lora_b = getattr(m, "lora_b", None) if self.rank > 0 else None
         self.scale = float(getattr(m, "scale", 1.0))
-        self.dora_m = getattr(m, "m", None) if self.rank > 0 else None
-        if self.dora_m is not None:
-            raise LlxError("DoRALinear inside a fused block is not supported yet; use LoRA (modelling/lora.py:47-62 is second priority)")
+        self.dora_m = getattr(m, "m", None) if self.rank > 0 else None  # DoRALinear's magnitude vector (modelling/lora.py:51)
         self.int8 = isinstance(self.weight, Int8LinearWeight)
         self.dynamic = bool(self.int8 and self.weight.dynamic_int8_act)
+        if self.dora_m is not None and self.int8:
+            # the reference cannot run this combination either: (weight + delta).norm() has no Int8LinearWeight dispatch (subclasses/int8.py:102)
+            raise LlxError("DoRA on an Int8LinearWeight is not supported (nor by the reference: no dispatch for weight + delta)")
         if self.rank > 64:
             raise LlxError(f"LoRA rank {self.rank} > 64 is not supported by the skinny kernels")
         if self.rank > 0 and self.lora_a.dtype is not BF16:
@@ -86,14 +87,28 @@ class LinearPlan:
             ts.append(self.bias)
         if self.rank > 0:
             ts += [self.lora_a, self.lora_b]
+        if self.dora_m is not None:
+            ts.append(self.dora_m)
         return ts
 
     # ---- forward: y = linear(x) [+ residual]; returns (y, saved) where saved is the LoRA intermediate t = x @ A^T
+    # (DoRA: the tuple (t, z, c, inv_norm) - un-scaled output, column scale m / ||W + sBA||, 1 / norm)
     def forward(self, x: Tensor, out: Optional[Tensor] = None, residual: Optional[Tensor] = None, gelu: bool = False):
         t = b2 = None
         if self.rank > 0:
             t = K.skinny_nt(x, self.lora_a.detach())
             b2 = K.pad64(self.lora_b.detach(), self.scale)
+        if self.dora_m is not None:
+            if gelu:
+                raise LlxError("DoRA + GELU epilogue is not supported")
+            w = self.weight.detach()
+            c, inv = dora_colscale([self], w, self.lora_a.detach(), b2)
+            z = K.gemm_nt(x, w, a2=t, b2=b2)
+            direct = residual is None
+            y = K.colscale_bias(z, c, self.bias.detach() if self.bias is not None else None, out=out if direct else None)
+            if residual is not None:
+                y = K.add(y, residual, out=out)
+            return y, (t, z, c, inv)
         if self.int8:
             from subclasses.int8 import int8_linear_forward
 
@@ -124,13 +139,19 @@ class LinearPlan:
         grads: list[Optional[Tensor]] = []
         ni = iter(needs)
         u = None
+        dy_out, gm = dy, None
+        if self.dora_m is not None:  # out = z * c (+ bias): d m = colsum(dy * z) / norm, and everything upstream sees dz = dy * c
+            t, z, c, inv = t
+            if needs[-1]:
+                gm = K.colsum_mul(dy, z, inv)
+            dy = K.scale(dy, colscale=c)
         if self.rank > 0:
             u = K.skinny_nt(dy, K.transpose(self.lora_b.detach()))  # dy @ B  -> [M,64]
         # --- parameter gradients, in tensors() order
         if not self.int8:
             grads.append(K.gemm_tn(dy, x) if next(ni) else None)
         if self.bias is not None:
-            grads.append(K.colsum(dy) if next(ni) else None)
+            grads.append(K.colsum(dy_out) if next(ni) else None)  # the bias is added after the DoRA rescale
         if self.rank > 0:
             need_a, need_b = next(ni), next(ni)
             ga = gb = None
@@ -141,6 +162,8 @@ class LinearPlan:
                 gb = torch.empty(self.N, self.rank, device=dy.device, dtype=BF16)
                 K.skinny_tn(t, dy, self.rank, self.scale, gb, transpose_out=True)
             grads += [ga, gb]
+        if self.dora_m is not None:
+            grads.append(gm)
         # --- data gradient
         dx = None
         if need_dx:
@@ -158,6 +181,24 @@ class LinearPlan:
             else:
                 dx = K.gemm_nt(g, wt, out=dx_out, a2=u, b2=b2)
         return dx, grads
+
+
+def dora_colscale(members: Sequence[LinearPlan], w_cat: Tensor, a_cat: Tensor, b2: Tensor) -> tuple[Tensor, Tensor]:
+    """DoRA's per-output-row factor for one linear or a fused group (modelling/lora.py:55-59, norm detached from A and B):
+    c [N] bf16 = m / ||W + s B A||_row and inv_norm [N] fp32, from ||W_n||^2 (cached with the frozen weight), G = W A^T and A A^T -
+    W is read once by the skinny MFMA kernel, no [out, in] temporary is formed.  b2 = the [N, 64] image of s * B (block diagonal)."""
+    N, R = w_cat.shape[0], a_cat.shape[0]
+    wn2 = _cached_multi([m.weight for m in members], "wn2", lambda: K.rownorm2(w_cat))
+    G = K.skinny_nt(w_cat, a_cat)
+    AAt = K.skinny_nt(a_cat, a_cat)
+    c = torch.empty(N, device=w_cat.device, dtype=BF16)
+    inv = torch.empty(N, device=w_cat.device, dtype=torch.float32)
+    off = 0
+    for m in members:
+        sl = slice(off, off + m.N)
+        K.dora_colscale(wn2[sl], G[sl], b2[sl], AAt, m.dora_m.detach(), c[sl], inv[sl], R)
+        off += m.N
+    return c, inv
 
 
 def _cached_multi(tensors: Sequence[Tensor], tag: str, build):
@@ -194,8 +235,10 @@ class GroupPlan:
         same_kind = all((m.int8, m.dynamic) == (m0.int8, m0.dynamic) for m in self.members)
         same_scale = len({m.scale for m in self.members if m.rank > 0}) <= 1
         lora_all_or_none = all(r > 0 for r in self.ranks) or self.R == 0
-        self.fused = (same_kind and same_scale and lora_all_or_none and self.R <= 64 and all(m.bias is None for m in self.members)
-                      and all(m.K == self.K for m in self.members))
+        dora_all_or_none = len({m.dora_m is not None for m in self.members}) == 1
+        self.dora = all(m.dora_m is not None for m in self.members)
+        self.fused = (same_kind and same_scale and lora_all_or_none and dora_all_or_none and self.R <= 64
+                      and all(m.bias is None for m in self.members) and all(m.K == self.K for m in self.members))
         self.int8, self.dynamic = m0.int8, m0.dynamic
         self.scale = next((m.scale for m in self.members if m.rank > 0), 1.0)
 
@@ -233,7 +276,11 @@ class GroupPlan:
 
     def rope_fusable(self) -> bool:
         """apply_rope can ride in the projection GEMM's epilogue (one fused bf16 GEMM writes the whole q|k|v row)."""
-        return self.fused and (not self.int8 or self.dynamic)
+        return self.fused and (not self.int8 or self.dynamic) and not self.dora
+
+    def swiglu_fusable(self) -> bool:
+        """silu(g) * u can ride in the gate|up GEMM's epilogue."""
+        return self.fused and (not self.int8 or self.dynamic) and not self.dora and len(self.members) == 2 and self.Ns[0] % 128 == 0
 
     def _forward(self, x: Tensor, out: Tensor, residual: Optional[Tensor], swiglu_h: Optional[Tensor] = None,
                  rope: Optional[tuple[Tensor, int, int]] = None):
@@ -246,6 +293,16 @@ class GroupPlan:
             a_cat, b2, bT, a2t = K.lora_group_pack([m.lora_a.detach() for m in self.members], [m.lora_b.detach() for m in self.members],
                                                    self.K, self.scale)
             t = (K.skinny_nt(x, a_cat), bT, a2t)
+        if self.dora:
+            # DoRA members: the un-scaled product z is kept for d m; rescale (and residual) are their own HBM-bound passes, so RoPE /
+            # SwiGLU run stand-alone after this group (rope_fusable / swiglu_fusable are False)
+            assert swiglu_h is None and rope is None
+            c, inv = dora_colscale(self.members, self.w_cat(), a_cat, b2)
+            z = K.gemm_nt(x, self.w_cat(), a2=t[0], b2=b2)
+            K.scale(z, colscale=c, out=out)
+            if residual is not None:
+                K.add(out, residual, out=out)
+            return (*t, z, c, inv)
         if not self.int8:
             if residual is not None:
                 K.gemm_nt(x, self.w_cat(), out=out, a2=t[0] if t else None, b2=b2, epilogue=K.EPI_RESIDUAL, e=residual)
@@ -320,20 +377,28 @@ class GroupPlan:
                 dx = d if d is not None else dx
                 first = False
             return dx, grads
-        t, bT, a2t = saved if saved is not None else (None, None, None)
-        u = gA = gBt = None
-        gB_views: Optional[list[Optional[Tensor]]] = None
+        gM = None
         ni = iter(needs)
         need = []
         for m in self.members:
             cnt = len(m.tensors())
             need.append([next(ni) for _ in range(cnt)])
+        ia = -3 if self.dora else -2  # per-member needs end with (..., lora_a, lora_b[, m])
+        if self.dora:  # out = z * c: d m = colsum(dy * z) / norm; everything upstream sees dz = dy * c
+            t, bT, a2t, z, c, inv = saved
+            if any(nd[-1] for nd in need):
+                gM = K.colsum_mul(dy, z, inv)
+            dy = K.scale(dy, colscale=c)
+        else:
+            t, bT, a2t = saved if saved is not None else (None, None, None)
+        u = gA = gBt = None
+        gB_views: Optional[list[Optional[Tensor]]] = None
         if self.R > 0:
             u = K.skinny_nt(dy, bT, self._kranges())  # [M,64]: column block i = dy_i @ B_i
-            if any(nd[-2] for nd in need):
+            if any(nd[ia] for nd in need):
                 gA = torch.empty(self.R, self.K, device=dy.device, dtype=BF16)
                 K.skinny_tn(u, x, self.R, self.scale, gA, transpose_out=False)
-            if any(nd[-1] for nd in need):
+            if any(nd[ia + 1] for nd in need):
                 segs = self._tn_segs()
                 if segs is not None:  # each member's dB lands in its own contiguous block of one flat buffer: no slicing copies
                     flat = torch.empty(sum((b - a) * (d - c) for a, b, c, d in segs), device=dy.device, dtype=BF16)
@@ -359,6 +424,9 @@ class GroupPlan:
                     gb_i += 1
                 else:
                     grads.append(gBt[no : no + n, ro : ro + m.rank].contiguous() if nd[j + 1] else None)
+                j += 2
+            if m.dora_m is not None:
+                grads.append(gM[no : no + n] if nd[j] else None)
         dx = None
         if need_dx:
             g = K.scale(dy, colscale=self.scale_cat()) if self.int8 else dy  # (g * scale) rounded (subclasses/int8.py:127)
@@ -436,22 +504,6 @@ class LinearFn(Function):
 
 def linear(x: Tensor, m: nn.Linear) -> Tensor:
     plan = LinearPlan(m)
-    return LinearFn.apply(x, plan, *plan.tensors())
-
-
-def linear_lora_nobias(x: Tensor, m: nn.Linear) -> Tensor:
-    """F.linear(x, W) + LoRA term without the bias and without the DoRA rescale (DoRALinear composes the rest)."""
-    plan = LinearPlan.__new__(LinearPlan)
-    saved_m, saved_b = m.__dict__.get("_parameters", {}).get("m"), m.bias
-    try:
-        if saved_m is not None:
-            del m._parameters["m"]
-        m._parameters["bias"] = None
-        plan.__init__(m)
-    finally:
-        m._parameters["bias"] = saved_b
-        if saved_m is not None:
-            m._parameters["m"] = saved_m
     return LinearFn.apply(x, plan, *plan.tensors())
 
 
@@ -585,7 +637,7 @@ class MLPBlockFn(Function):
             xn, rstd = x2, None
         T, I = x2.shape[0], meta.w13.Ns[0]
         gu = torch.empty(T, 2 * I, device=x.device, dtype=BF16)
-        if meta.w13.fused and (not meta.w13.int8 or meta.w13.dynamic) and len(meta.w13.members) == 2 and I % 128 == 0 and _FUSE_SWIGLU_FWD:
+        if meta.w13.swiglu_fusable() and _FUSE_SWIGLU_FWD:
             h = torch.empty(T, I, device=x.device, dtype=BF16)
             _, t13 = meta.w13.forward(xn, gu, swiglu_h=h)  # SwiGLU in the epilogue of the gate|up GEMM
         else:

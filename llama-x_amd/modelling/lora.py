@@ -46,9 +46,9 @@ class LoRALinear(nn.Linear):
 class DoRALinear(LoRALinear):
     """Weight-decomposed LoRA: (W x + s B A x) * m / ||W + s B A||_row + bias (reference modelling/lora.py:47-62).
 
-    Second-priority path: the LoRA part runs on the fused HIP GEMM; the per-row norm factor (no gradient flows
-    through it except via ``m``) is assembled with device tensor ops on top of it.
-    """
+    The row norm is evaluated on the device without the reference's dense [out, in] temporary (csrc/dora.hip: ||W_n||^2 cached,
+    cross term through the skinny MFMA kernel); the rescale, the bias and the gradient of ``m`` are HIP kernels behind
+    ``llx.ops.LinearPlan`` - stand-alone and inside the fused transformer blocks alike."""
 
     def init_adapter(self, rank: int = 8, alpha: float = 8.0) -> None:
         super().init_adapter(rank, alpha)
@@ -56,12 +56,4 @@ class DoRALinear(LoRALinear):
             self.m = nn.Parameter(self.weight.norm(p=2, dim=1))
 
     def forward(self, x: Tensor):
-        if self.rank <= 0:
-            return ops.linear(x, self)
-        out = ops.linear_lora_nobias(x, self)
-        delta = (self.lora_b.detach() @ self.lora_a.detach()) * self.scale
-        norm = (self.weight + delta).norm(p=2, dim=1)
-        out = out * (self.m / norm)
-        if self.bias is not None:
-            out = out + self.bias
-        return out
+        return ops.linear(x, self)

@@ -266,6 +266,38 @@ yd = lin(xd)
 close(O.dora_linear(xd, lin.weight, lin.lora_a, lin.lora_b, lin.m, 2.0, lin.bias), yd, 1e-5, "dora")
 save("g08_dora", y=yd, m=lin.m)
 
+# DoRA on every linear of the layers (apply_linear_adapter_(model.layers, "dora"), the scripts' --adapter dora): loss and the gradients
+# of m / lora_a / lora_b through the whole model
+lp = O.init_lora(CFG, 8)
+m = ref_model(params)
+for q in m.parameters():
+    q.requires_grad_(False)
+RM.apply_linear_adapter_(m.layers, "dora", rank=8, alpha=16.0)
+dp_ = dict(params)
+dm_ = O.init_dora_m(params, CFG)
+with torch.no_grad():
+    for name, mod in m.layers.named_modules():
+        if f"layers.{name}.lora_a" in lp:
+            mod.lora_a.copy_(lp[f"layers.{name}.lora_a"])
+            mod.lora_b.copy_(lp[f"layers.{name}.lora_b"])
+            close(mod.m, mod.weight.norm(p=2, dim=1), 1e-6, "dora m init")  # the reference initialises m = ||W||_row (lora.py:51)
+            mod.m.copy_(dm_[f"layers.{name}.m"])  # then moved off that value
+            dp_[f"layers.{name}.m"] = mod.m.detach().clone().requires_grad_()
+dp_.update({k: v.clone().requires_grad_() for k, v in lp.items()})
+loss_d = m(tokens, labels=labels)
+loss_d.backward()
+lo_d = O.llama_forward(tokens, dp_, CFG, labels=labels, lora_scale=2.0)
+lo_d.backward()
+close(lo_d, loss_d, 1e-6, "dora model loss")
+out = {"loss": loss_d}
+for name, q in m.named_parameters():
+    if q.requires_grad:
+        close(dp_[name].grad, q.grad, 5e-5, f"dora grad {name}")
+for name in ("layers.0.attention.wq.m", "layers.0.attention.wq.lora_a", "layers.1.feed_forward.w2.m", "layers.1.feed_forward.w1.lora_b",
+             "layers.0.attention.wv.m"):
+    out[name.replace(".", "_")] = dict(m.named_parameters())[name].grad
+save("g08_dora_model", **out)
+
 # ------------------------------------------------------------------------------------------------- G9 int8
 for dt in (torch.float32, torch.bfloat16):
     w8 = O.randn("q_w", (96, 512), 0.05).to(dt)

@@ -142,6 +142,17 @@ def init_lora(cfg: Cfg, rank: int, *, seed: int = 1234, dtype=torch.float32, b_s
     return p
 
 
+def init_dora_m(p: dict, cfg: Cfg) -> dict[str, Tensor]:
+    """DoRA magnitude vectors for every linear of the layers: the reference's initial value ||W||_row (modelling/lora.py:51)
+    moved off it by a seeded +-10 % factor, so that tests see m != norm."""
+    out = {}
+    for i in range(cfg.num_layers):
+        for suf in LINEAR_SUFFIXES:
+            w = p[f"layers.{i}.{suf}.weight"].float()
+            out[f"layers.{i}.{suf}.m"] = w.norm(p=2, dim=1) * (1 + 0.1 * randn(f"dora_m.{i}.{suf}", (w.shape[0],)))
+    return out
+
+
 # --------------------------------------------------------------------------------------------------
 # RoPE  (modelling/llama.py:32-73)
 # --------------------------------------------------------------------------------------------------
@@ -232,6 +243,8 @@ def sdpa(q: Tensor, k: Tensor, v: Tensor, mask: Optional[Tensor]) -> Tensor:
 def linear(x: Tensor, p: dict, key: str, lora_scale: float = 1.0) -> Tensor:
     """F.linear with optional LoRA / int8 dressing found in ``p`` under ``key`` (modelling/lora.py:40-44,
     subclasses/int8.py:106-121).  Adapter order follows LoRALinear.forward: base + ((x@A^T)@B^T)*scale."""
+    if key + ".m" in p:  # DoRALinear (modelling/lora.py:47-62); dora_linear is defined below
+        return dora_linear(x, p[key + ".weight"], p[key + ".lora_a"], p[key + ".lora_b"], p[key + ".m"], lora_scale, p.get(key + ".bias"))
     if key + ".int_data" in p:
         out = int8_linear(x, p[key + ".int_data"], p[key + ".scale"], dynamic=bool(p.get(key + ".dynamic", False)))
     else:

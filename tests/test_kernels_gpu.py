@@ -523,3 +523,164 @@ def test_gemm_race_screen(K, cuda):
         outs = [K.gemm_nt(a, b, a2=a2, b2=b2, epilogue=K.EPI_RESIDUAL, e=e) for _ in range(3)]
         assert all(torch.equal(outs[0], o) for o in outs[1:]), (M, N, Kd, K2)
         torch.testing.assert_close(outs[0].float(), ref, atol=2 ** -6 * ref.abs().max().item(), rtol=2 ** -6)
+
+
+# ------------------------------------------------------------------------------------------------- int8: integer parity at the boundary
+GOLD = __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.abspath(__file__)), "golden")
+
+
+def _gold(name):
+    import numpy as np
+
+    return {k: torch.from_numpy(v) for k, v in np.load(f"{GOLD}/{name}.npz").items()}
+
+
+def test_quantize_int8_rowwise_hip_bit_exact(cuda):
+    """A19 / K12: `subclasses.int8.quantize_int8_rowwise` on DEVICE tensors (csrc/int8_quant.hip) against the reference's golden
+    vector (g09_quant_bf16: [96,512] bf16 with an all-zero row) and against the oracle (reference subclasses/int8.py:10-16) on
+    fp32 input, on the activation shapes of the dynamic path ([4096,4096], [4096,14336]), on a row-strided view and on exact
+    half-way ties (round half to even).  Integer work: `torch.equal` on both q and scale."""
+    from subclasses.int8 import quantize_int8_rowwise
+
+    g = _gold("g09_quant_bf16")
+    for dt in (torch.bfloat16, torch.float32):
+        w = O.randn("q_w", (96, 512), 0.05).to(dt)
+        w[5] = 0
+        q, s = quantize_int8_rowwise(w.to(cuda))
+        assert q.dtype is torch.int8 and s.dtype is dt and q.is_cuda
+        qo, so = O.quantize_int8_rowwise(w)
+        assert torch.equal(q.cpu(), qo) and torch.equal(s.cpu(), so), f"HIP quantiser differs from the oracle ({dt})"
+        if dt is torch.bfloat16:
+            assert torch.equal(q.cpu(), g["q"]) and torch.equal(s.cpu().float(), g["scale"]), "HIP quantiser differs from the reference's golden vector"
+            assert int(q[5].abs().sum()) == 0 and float(s[5]) == 0.0  # the 1e-12 clip on an all-zero row
+    for shape in ((4096, 4096), (4096, 14336)):
+        x = O.randn(f"q_act{shape[1]}", shape, 1.3).bfloat16()
+        x[7, 11] = 40.0  # an outlier row
+        q, s = quantize_int8_rowwise(x.to(cuda))
+        qo, so = O.quantize_int8_rowwise(x)
+        assert torch.equal(q.cpu(), qo) and torch.equal(s.cpu(), so), f"activation shape {shape}"
+    # rows of a wider buffer (row stride 1024, 520 columns: ragged tail of the 16-byte vector loop)
+    buf = O.randn("q_strided", (33, 1024)).bfloat16()
+    v = buf.to(cuda)[:, 8:528]
+    q, s = quantize_int8_rowwise(v)
+    qo, so = O.quantize_int8_rowwise(buf[:, 8:528])
+    assert torch.equal(q.cpu(), qo) and torch.equal(s.cpu(), so)
+    # exact ties: absmax 127 -> scale 1.0, x / scale = k + 0.5 -> round half to even
+    t = torch.zeros(2, 64)
+    t[:, 0] = 127.0
+    t[0, 1:9] = torch.tensor([0.5, 1.5, 2.5, 3.5, -0.5, -1.5, -2.5, 126.5])
+    t[1, 1:5] = torch.tensor([-126.5, 63.5, 64.5, -3.5])
+    for dt in (torch.bfloat16, torch.float32):
+        q, s = quantize_int8_rowwise(t.to(dt).to(cuda))
+        qo, so = O.quantize_int8_rowwise(t.to(dt))
+        assert torch.equal(q.cpu(), qo) and torch.equal(s.cpu(), so)
+        assert q[0, 1:9].tolist() == [0, 2, 2, 4, 0, -2, -2, 126] and q[1, 1:5].tolist() == [-126, 64, 64, -4]
+
+
+def test_int8_mm_dequant_registered_op_with_transposed_view(cuda):
+    """A23 at the boundary the reference binds: `torch.ops.torchao.int8_mm_dequant(A, W.T, a_scale, b_scale)` with B the
+    NON-contiguous `.T` view (strides (1, K), reference call site subclasses/int8.py:113) through the registered "CUDA" (= HIP)
+    implementation, bit-exact against the golden vector g10_int8_mm; also a contiguous [K, N] B and the python wrapper's asserts."""
+    from subclasses.int8_mm import int8_mm_dequant
+
+    g = _gold("g10_int8_mm")
+    a8 = O.randint("mm_a", (70, 256), -127, 128).to(torch.int8).to(cuda)
+    b8 = O.randint("mm_b", (96, 256), -127, 128).to(torch.int8).to(cuda)
+    sa = O.uniform("mm_sa", (70,), 0.001, 0.02).bfloat16().to(cuda)
+    sb = O.uniform("mm_sb", (96,), 0.001, 0.02).bfloat16().to(cuda)
+    Bv = b8.T
+    assert Bv.stride() == (1, 256) and not Bv.is_contiguous()
+    c = torch.ops.torchao.int8_mm_dequant(a8, Bv, sa, sb)
+    assert c.shape == (70, 96) and c.dtype is torch.bfloat16 and c.is_cuda
+    assert torch.equal(c.cpu().float(), g["c"]), "registered op differs from the golden vector"
+    assert torch.equal(int8_mm_dequant(a8, Bv, sa, sb), c)                       # python wrapper (asserts of int8_mm.py:124-132)
+    assert torch.equal(int8_mm_dequant(a8, Bv.contiguous(), sa, sb), c)          # a row-major [K, N] B is re-laid out
+    assert torch.equal(int8_mm_dequant(a8, Bv, sa.view(70, 1), sb.view(1, 96)), c)  # keepdim scales (.squeeze() in the asserts)
+    with pytest.raises(AssertionError):
+        int8_mm_dequant(a8, Bv, sa.float(), sb)
+    # a production shape: activations [4096, 4096] x W[1024, 4096].T, against the oracle's integer restatement
+    A = O.randint("mm_A", (4096, 4096), -127, 128).to(torch.int8)
+    W = O.randint("mm_W", (1024, 4096), -127, 128).to(torch.int8)
+    s1 = O.uniform("mm_s1", (4096,), 0.001, 0.02).bfloat16()
+    s2 = O.uniform("mm_s2", (1024,), 0.001, 0.02).bfloat16()
+    big = torch.ops.torchao.int8_mm_dequant(A.to(cuda), W.to(cuda).T, s1.to(cuda), s2.to(cuda))
+    assert torch.equal(big.cpu(), O.int8_mm_dequant(A, W.T, s1, s2))
+
+
+@pytest.mark.parametrize("dynamic", [False, True])
+def test_f_linear_on_int8_weight(cuda, dynamic):
+    """A20/A21: `F.linear(x, Int8LinearWeight)` through `__torch_function__` -> `_Int8Linear` on the GPU, forward and backward.
+    Weight-only mode against the reference's own output (g09_int8_linear; the reference's CPU bf16 matmul and the MFMA GEMM sum in
+    different orders, so the product may round differently by one bf16 ulp before the `* scale`); dynamic mode against the oracle
+    bit for bit (integer product, single rounding)."""
+    import torch.nn.functional as F
+
+    from subclasses import Int8LinearWeight
+
+    g = _gold("g09_int8_linear")
+    wf = O.randn("i8_w", (256, 512), 0.05).bfloat16()
+    w_host = Int8LinearWeight.from_float(wf, dynamic_int8_act=dynamic)        # host branch of the quantiser
+    w_dev = Int8LinearWeight.from_float(wf.to(cuda), dynamic_int8_act=dynamic)  # HIP quantiser
+    assert torch.equal(w_dev.int_data.cpu(), w_host.int_data) and torch.equal(w_dev.scale.cpu(), w_host.scale)
+    assert torch.equal(w_dev.dequantize().cpu()[::8, ::8].float(), g["dequant_slice"])
+    w = w_host.to(cuda)  # _to_copy dispatch
+    assert isinstance(w, Int8LinearWeight) and w.int_data.is_cuda and w.dynamic_int8_act == dynamic
+    x = O.randn("i8_x", (40, 512)).bfloat16().to(cuda).requires_grad_()
+    gy = O.randn("i8_g", (40, 256)).bfloat16().to(cuda)
+    y = F.linear(x, w, None)
+    y.backward(gy)
+    xo = O.randn("i8_x", (40, 512)).bfloat16().requires_grad_()
+    yo = O.int8_linear(xo, w_host.int_data, w_host.scale, dynamic=dynamic)
+    yo.backward(gy.cpu())
+    ulp = 2.0 ** -7  # one bf16 ulp relative to the value's binade
+    tol = lambda ref: dict(atol=2.0 ** -9 * ref.abs().max().item(), rtol=2 * ulp)  # noqa: E731  (two roundings: product, then * scale)
+    if dynamic:
+        assert torch.equal(y.detach().cpu(), yo.detach()), "dynamic int8 forward must be bit-exact"
+    else:
+        torch.testing.assert_close(y.detach().cpu().float(), g["y"], **tol(g["y"]))
+        torch.testing.assert_close(y.detach().cpu().float(), yo.detach().float(), **tol(g["y"]))
+    # backward is always the bf16 dequantised product (subclasses/int8.py:124-127): one-ulp agreement with the reference's dx
+    torch.testing.assert_close(x.grad.cpu().float(), g["dx"], **tol(g["dx"]))
+    # 3-D input and a bias go through the same path
+    x3 = O.randn("i8_x3", (2, 20, 512)).bfloat16().to(cuda)
+    bias = O.randn("i8_bias", (256,), 0.1).bfloat16().to(cuda)
+    y3 = F.linear(x3, w, bias)
+    want = O.int8_linear(x3.cpu(), w_host.int_data, w_host.scale, dynamic=dynamic, bias=bias.cpu())
+    torch.testing.assert_close(y3.cpu().float(), want.float(), **tol(want.float()))
+
+
+# ------------------------------------------------------------------------------------------------- DoRA kernels
+@pytest.mark.parametrize("N,Kd,ranks", [(256, 512, (8,)), (6144, 4096, (16, 16, 16)), (1792, 512, (8, 8))])
+def test_dora_colscale_and_dm(K, cuda, N, Kd, ranks):
+    """csrc/dora.hip: c = m / ||W + s B A||_row from the expanded square (no dense temporary) against the dense fp32 evaluation
+    of modelling/lora.py:55-59, for one linear and for the block-diagonal operands of a fused group; d m = colsum(dy * z) / norm."""
+    nm = len(ranks)
+    Ns = [N // nm] * nm
+    s = 2.0
+    W = O.randn("dk_w", (N, Kd), 0.05).bfloat16()
+    As = [O.randn(f"dk_a{i}", (r, Kd), 0.05).bfloat16() for i, r in enumerate(ranks)]
+    Bs = [O.randn(f"dk_b{i}", (n, r), 0.05).bfloat16() for i, (n, r) in enumerate(zip(Ns, ranks))]
+    m = (W.float().norm(dim=1) * (1 + 0.1 * O.randn("dk_m", (N,)))).bfloat16()
+    a_cat, b2, _, _ = K.lora_group_pack([a.to(cuda) for a in As], [b.to(cuda) for b in Bs], Kd, s)
+    wd = W.to(cuda)
+    wn2 = K.rownorm2(wd)
+    torch.testing.assert_close(wn2.cpu(), W.float().pow(2).sum(1), rtol=1e-5, atol=1e-6)
+    G, AAt = K.skinny_nt(wd, a_cat), K.skinny_nt(a_cat, a_cat)
+    c = torch.empty(N, device=cuda, dtype=torch.bfloat16)
+    inv = torch.empty(N, device=cuda, dtype=torch.float32)
+    off = 0
+    for n in Ns:
+        sl = slice(off, off + n)
+        K.dora_colscale(wn2[sl], G[sl], b2[sl], AAt, m.to(cuda)[sl].contiguous(), c[sl], inv[sl], sum(ranks))
+        off += n
+    norm = torch.cat([(W[o : o + n].float() + s * (b.float() @ a.float())).norm(dim=1) for o, n, a, b in zip(range(0, N, Ns[0]), Ns, As, Bs)])
+    torch.testing.assert_close(1.0 / inv.cpu(), norm, rtol=2 ** -7, atol=0)       # the norm is a bf16 tensor in the eager graph
+    torch.testing.assert_close(c.cpu().float(), m.float() / norm, rtol=2 ** -6, atol=0)
+    M = 300
+    dy, z = O.randn("dk_dy", (M, N)).bfloat16(), O.randn("dk_z", (M, N)).bfloat16()
+    dm = K.colsum_mul(dy.to(cuda), z.to(cuda), inv)
+    want = (dy.float() * z.float()).sum(0) * inv.cpu()
+    torch.testing.assert_close(dm.cpu().float(), want, rtol=2 ** -7, atol=2 ** -8 * want.abs().max().item())
+    y = K.colscale_bias(z.to(cuda), c, m.to(cuda))
+    want = ((z.float() * c.cpu().float()).bfloat16().float() + m.float()).bfloat16()
+    assert torch.equal(y.cpu(), want)

@@ -26,6 +26,20 @@ def _close(a, b, rel, name):
     assert err <= rel * scale + 1e-6, f"{name}: max err {err:.4e} vs scale {scale:.4e} (allowed {rel * scale:.4e})"
 
 
+def _rows_close(a, b, name, min_cos=0.999, floor=1e-3):
+    """Per-row check next to the max-norm one: every row (last dim) of `a` must point the same way as the reference row and have
+    the same length - an error confined to small-magnitude rows (a dropped LoRA row block, a mis-rotated head) passes `_close` but
+    not this.  Rows whose reference norm is below `floor` x the largest row norm carry rounding noise only and are skipped."""
+    a2, b2 = a.reshape(-1, a.shape[-1]).double(), b.reshape(-1, b.shape[-1]).double()
+    nb = b2.norm(dim=1)
+    keep = nb > floor * nb.max()
+    cos = (a2 * b2).sum(1) / (a2.norm(dim=1) * nb).clamp_min(1e-30)
+    worst = cos[keep].min().item()
+    assert worst >= min_cos, f"{name}: worst per-row cosine {worst:.5f} < {min_cos} (row {int(cos.masked_fill(~keep, 2).argmin())})"
+    ratio = (a2.norm(dim=1) / nb.clamp_min(1e-30))[keep]
+    assert (ratio - 1).abs().max().item() < 0.05, f"{name}: per-row norm ratio off by {(ratio - 1).abs().max().item():.4f}"
+
+
 def test_logits_causal(cuda):
     pb, pf = bf16_params(O.init_params(CFG))
     tokens, _ = _data(2, 256)
@@ -75,6 +89,8 @@ def test_lora_loss_and_grads(cuda, rank):
         if prm.requires_grad:
             assert prm.grad is not None, name
             _close(prm.grad.float().cpu(), pr[name].grad, 0.04, name)
+            if prm.grad.dim() == 2:
+                _rows_close(prm.grad.float().cpu(), pr[name].grad, name, min_cos=0.995)
         else:
             assert prm.grad is None, name
 
@@ -284,7 +300,8 @@ def test_trainer_accumulation_clip_schedule_and_checkpoint(cuda, tmp_path):
 
 
 def test_dora_linear_standalone(cuda):
-    """A18: DoRALinear.forward (second priority) = fused LoRA GEMM + row-norm rescale; compared with the oracle / golden."""
+    """A18: DoRALinear.forward stand-alone (with a bias) = fused LoRA GEMM + HIP row-norm rescale; forward against the REFERENCE's
+    golden output, gradients of x / m / lora_a / lora_b / bias against the oracle (modelling/lora.py:53-62)."""
     import numpy as np
     import os
 
@@ -298,13 +315,25 @@ def test_dora_linear_standalone(cuda):
     apply_linear_adapter_(lin, "dora", rank=8, alpha=16.0)
     lin.lora_a.data.copy_(O.randn("dora_a", (8, 512), 0.05))
     lin.lora_b.data.copy_(O.randn("dora_lb", (256, 8), 0.05))
+    torch.testing.assert_close(lin.m.detach().float(), torch.from_numpy(g["m"]), rtol=2 ** -7, atol=0)
     lin = lin.to(cuda)
+    lin.bias.requires_grad_(True)
     x = O.randn("dora_x", (40, 512)).bfloat16()
-    y = lin(x.to(cuda))
+    xg = x.to(cuda).requires_grad_()
+    y = lin(xg)
     ref = torch.from_numpy(g["y"])
     _close(y.float().cpu(), ref, 0.03, "DoRA forward vs reference golden")
-    y.sum().backward()
-    assert lin.m.grad is not None and lin.lora_a.grad is not None and lin.weight.grad is None
+    dy = O.randn("dora_dy", (40, 256)).bfloat16()
+    y.backward(dy.to(cuda))
+    t = {k: getattr(lin, k).detach().float().cpu().requires_grad_() for k in ("lora_a", "lora_b", "m", "bias")}
+    xo = x.float().requires_grad_()
+    yo = O.dora_linear(xo, lin.weight.detach().float().cpu(), t["lora_a"], t["lora_b"], t["m"], 2.0, t["bias"])
+    yo.backward(dy.float())
+    _close(y.float().cpu(), yo.detach(), 0.02, "DoRA forward vs oracle")
+    _close(xg.grad.float().cpu(), xo.grad, 0.03, "DoRA dx")
+    for k, v in t.items():
+        _close(getattr(lin, k).grad.float().cpu(), v.grad, 0.03, "DoRA d" + k)
+    assert lin.weight.grad is None
 
 
 def test_kv_cache_prefill_and_decode(cuda):
@@ -346,11 +375,30 @@ def test_kv_cache_prefill_and_decode(cuda):
         layer(hid.to(cuda).requires_grad_(), model.rope[:384], mask=dense.to(cuda))
 
 
-@pytest.mark.parametrize("S", [512, 2048])
-def test_full_dimension_layer_parity(cuda, S):
-    """One TransformerLayer at the REAL Llama-3.1-8B dimensions (D 4096, 32/8 heads, I 14336, LoRA r=16) against the oracle:
-    exercises the production tile shapes (N = 6144 / 28672 fused groups with RoPE / SwiGLU epilogues, K-extension, block-diagonal
-    LoRA operands, GQA 4:1, multi-tile causal attention; S = 2048 adds multi-round GEMM grids and 16-tile key sweeps)."""
+def _mask_for(kind, S):
+    """(dense bool oracle mask | None, MaskSpec | None) for the layer-parity cases."""
+    from modelling.llama import MaskSpec
+
+    if kind == "causal":
+        return None, None
+    if kind == "doc":  # packed documents of uneven length + the packer's id-0 tail (train_metamathqa.py:51-83)
+        doc = torch.zeros(S, dtype=torch.int64)
+        for c in (S // 16 + 5, S // 3 + 77, S // 2 - 130, (7 * S) // 8 + 9):
+            doc[c:] += 1
+        doc[S - 100 :] = 0
+        return O.document_mask(doc), MaskSpec(doc_ids=doc)
+    if kind == "prefix":  # prefix-LM: bidirectional over the first P positions (P not a multiple of the 64/128 tiles)
+        P = S // 2 - 56
+        return O.prefix_lm_mask(S, [P])[0, 0], MaskSpec(prefix_len=torch.tensor([P]))
+    raise ValueError(kind)
+
+
+@pytest.mark.parametrize("S,kind", [(512, "causal"), (2048, "causal"), (4096, "causal"), (4096, "doc"), (4096, "prefix"), (8192, "causal")])
+def test_full_dimension_layer_parity(cuda, S, kind):
+    """One TransformerLayer at the REAL Llama-3.1-8B dimensions (D 4096, 32/8 heads, I 14336, LoRA r=16) against the oracle, at
+    the sequence lengths BASELINE.json's configs run (S = 4096 headline, S = 8192 for configs[4]) and with the three mask kinds
+    (causal, packed-document, prefix-LM): exercises the production tile shapes (N = 6144 / 28672 fused groups with RoPE / SwiGLU
+    epilogues, K-extension, block-diagonal LoRA operands, GQA 4:1, 64-128-tile causal key sweeps, multi-round GEMM grids)."""
     from modelling import apply_linear_adapter_
     from modelling.llama import LlamaConfig, TransformerLayer, build_rope
 
@@ -363,7 +411,8 @@ def test_full_dimension_layer_parity(cuda, S):
     train = [k for k in pf if "lora_" in k or k.endswith("_norm.weight")]
     pr = {k: (v.clone().requires_grad_() if k in train else v) for k, v in pf.items()}
     xr = x.float().requires_grad_()
-    ref = O.layer(xr, pr, 0, cfg, O.rope_table(cfg)[:S], None, 1.0)
+    dense, spec = _mask_for(kind, S)
+    ref = O.layer(xr, pr, 0, cfg, O.rope_table(cfg)[:S], dense, 1.0)
     ref.backward(dy.float())
 
     layer = TransformerLayer(LlamaConfig(**{f: getattr(cfg, f) for f in LlamaConfig._fields})).bfloat16()
@@ -379,18 +428,22 @@ def test_full_dimension_layer_parity(cuda, S):
         q.requires_grad_("lora_" in n or n.endswith("_norm.weight"))
     rope = build_rope(LlamaConfig(**{f: getattr(cfg, f) for f in LlamaConfig._fields})).to(cuda)
     xg = x.to(cuda).requires_grad_()
-    out = layer(xg, rope[:S])
+    out = layer(xg, rope[:S], block_mask=spec)
     out.backward(dy.to(cuda))
     _close(out.float().cpu(), ref.detach(), 0.02, "layer output at 8B dims")
+    _rows_close(out.float().cpu(), ref.detach(), "layer output rows")
     _close(xg.grad.float().cpu(), xr.grad, 0.04, "dx at 8B dims")
+    _rows_close(xg.grad.float().cpu(), xr.grad, "dx rows", min_cos=0.998)
     for name, q in layer.named_parameters():
         if q.requires_grad:
             _close(q.grad.float().cpu(), pr["layers.0." + name].grad, 0.05, name)
+            if q.grad.dim() == 2:
+                _rows_close(q.grad.float().cpu(), pr["layers.0." + name].grad, name, min_cos=0.995)
     # determinism at full size: a second run is bit-identical (no atomics anywhere on the path)
     xg2 = x.to(cuda).requires_grad_()
     for q in layer.parameters():
         q.grad = None
-    out2 = layer(xg2, rope[:S])
+    out2 = layer(xg2, rope[:S], block_mask=spec)
     out2.backward(dy.to(cuda))
     assert torch.equal(out2, out) and torch.equal(xg2.grad, xg.grad)
 
@@ -413,3 +466,164 @@ def test_packed_iterator_with_prefetch_trains(cuda):
             loss = model(inputs, labels=labels, block_mask=ms)
         ref = O.llama_forward(hi, pf, CFG, mask=O.document_mask(hm.doc_ids.cpu().long().view(-1))[None, None], labels=hl)
         assert abs(loss.item() - ref.item()) < 3e-3 * max(1.0, abs(ref.item())), (loss.item(), ref.item())
+
+
+# ------------------------------------------------------------------------------------------------- configs[4]: mixed prefix, B > 1
+def test_audio_text_mixed_prefix_batch(cuda):
+    """BASELINE.json configs[4] in small: B = 2 early-fusion [audio ; text] sequences whose prefix lengths DIFFER per sample
+    (sample 0: all 100 audio tokens bidirectional, sample 1: a 1.2 s clip zero-padded to 2 s -> P = 60), text zero-padded to a
+    common length with -100 labels (LibriSpeech._prepare_batch, train_librispeech.py:68-86), LoRA r=8 on the layers and a trainable
+    audio_embed: loss, conv gradients and LoRA gradients against the oracle's dense per-sample prefix-LM mask."""
+    from llx import data as D
+    from modelling.llama import MaskSpec
+
+    p = O.init_params(CFG, audio=True)
+    p.update(O.init_lora(CFG, 8))
+    pb, pf = bf16_params(p)
+    clips = [O.uniform("audio0", (32000,), -0.1, 0.1), O.uniform("audio1", (19200,), -0.1, 0.1)]
+    toks = [[1] + O.randint("t0", (140,), 3, CFG.vocab_size).tolist() + [2], [1] + O.randint("t1", (87,), 3, CFG.vocab_size).tolist() + [2]]
+    audio, tokens, labels = D.prepare_audio_batch(list(zip(clips, toks)), 32000, 156, 0)  # text padded to 156 -> S = 100 + 156 = 256
+    assert tokens.shape == (2, 156) and (labels[1, 88:] == -100).all() and labels[0, 140] == 2
+    P = torch.tensor([100, 60])
+    S = 100 + tokens.shape[1]
+    mask = O.prefix_lm_mask(S, P)
+    assert mask.shape == (2, 1, S, S) and bool(mask[0, 0, 3, 99]) and not bool(mask[1, 0, 3, 99]) and bool(mask[1, 0, 3, 59])
+    train = [k for k in pf if "lora_" in k or k.startswith("audio_embed")]
+    pr = {k: (v.clone().requires_grad_() if k in train else v) for k, v in pf.items()}
+    mel = O.mel_spectrogram(audio)
+    ref = O.llama_audio_forward(None, tokens, pr, CFG, mel=mel, labels=labels, mask=mask, lora_scale=1.0)
+    ref.backward()
+    model = build_model(CFG, pb, cuda, lora_rank=8, audio=True)
+    for n, q in model.named_parameters():
+        q.requires_grad_("lora_" in n or n.startswith("audio_embed"))
+    loss = model(audio.to(cuda), tokens.to(cuda), labels=labels.to(cuda), block_mask=MaskSpec(prefix_len=P))
+    loss.backward()
+    assert abs(loss.item() - ref.item()) < 3e-3 * max(1.0, abs(ref.item())), (loss.item(), ref.item())
+    for name, q in model.named_parameters():
+        if q.requires_grad:
+            assert q.grad is not None, name
+            _close(q.grad.float().cpu(), pr[name].grad, 0.06, name)
+    # the per-sample prefix matters: the same batch under one shared prefix gives a different loss
+    with torch.no_grad():
+        other = model(audio.to(cuda), tokens.to(cuda), labels=labels.to(cuda), block_mask=MaskSpec(prefix_len=torch.tensor([100, 100])))
+    assert abs(other.item() - loss.item()) > 1e-4
+
+
+def test_audio_conv_stack_full_width(cuda):
+    """A12 / K16 at the production width: Conv1d(128 -> 4096, k3, s1) + GELU + Conv1d(4096 -> 4096, k3, s2) + GELU over a 20 s clip
+    as implicit GEMMs (M = 2000, K = 384, N = 4096 and M = 1000, K = 12288, N = 4096 over the stride-2 overlapping view; M is not a
+    multiple of the 256-row tile), forward and the hand-written backward (conv weights + biases), against the oracle's F.conv1d."""
+    from llx import audio_ops
+    from modelling import LlamaAudio
+    from tests.util import to_model_config
+
+    D = 4096
+    cfg = O.TINY._replace(embed_dim=D, num_layers=0, num_heads=32, num_kv_heads=8, intermediate_dim=256, vocab_size=64, max_seq_len=2048)
+    gen = {"audio_embed.0.weight": O.randn("c1w", (D, 128, 3), 0.05), "audio_embed.0.bias": O.randn("c1b", (D,), 0.05),
+           "audio_embed.2.weight": O.randn("c2w", (D, D, 3), 0.01), "audio_embed.2.bias": O.randn("c2b", (D,), 0.05),
+           "tok_embeddings.weight": O.randn("emb", (64, D), 0.02)}
+    pb, pf = bf16_params(gen)
+    audio = O.uniform("audio", (1, 320000), -0.1, 0.1)
+    tokens = O.randint("tokens", (1, 24), 0, 64)
+    mel = O.mel_spectrogram(audio)
+    pr = {k: v.clone().requires_grad_() for k, v in pf.items()}
+    feat = O.log_mel_cmn(mel).bfloat16().float()  # the product casts the features to the embedding dtype (modelling/audio.py:55)
+    ref = O.audio_embed(feat, pr)
+    assert ref.shape == (1, 1000, D)
+    dy = O.randn("conv_dy", (1, 1000, D), 0.1).bfloat16()
+    ref.backward(dy.float())
+    model = LlamaAudio(to_model_config(cfg)).bfloat16()
+    model.load_state_dict(pb, strict=False)
+    model.build_cache()
+    model = model.to(cuda)
+    x, n_audio = audio_ops.audio_prefix_and_embed(model, audio.to(cuda), tokens.to(cuda))
+    assert n_audio == 1000 and x.shape == (1, 1024, D)
+    _close(x[:, :1000].float().cpu(), ref.detach(), 0.02, "conv stack output at D=4096")
+    _rows_close(x[:, :1000].float().cpu(), ref.detach(), "conv stack rows", min_cos=0.999)
+    assert torch.equal(x[0, 1000:].cpu(), pb["tok_embeddings.weight"][tokens[0]])  # the gather lands behind the audio prefix
+    g = torch.zeros_like(x)
+    g[:, :1000] = dy.to(cuda)
+    x.backward(g)
+    for name in ("audio_embed.0.weight", "audio_embed.0.bias", "audio_embed.2.weight", "audio_embed.2.bias"):
+        got = dict(model.named_parameters())[name].grad.float().cpu()
+        _close(got, pr[name].grad, 0.03, name)
+        if got.dim() == 3:
+            _rows_close(got.flatten(1), pr[name].grad.flatten(1), name, min_cos=0.998, floor=0.02)
+
+
+# ------------------------------------------------------------------------------------------------- K18 activation checkpointing
+def test_activation_checkpointing_bit_identical_and_saves_memory(cuda):
+    """LlamaConfig.activation_checkpointing=True (modelling/llama.py:209-212: non-reentrant checkpoint per layer): every activation
+    of the fused blocks goes through save_for_backward, so the checkpoint drops them and recomputes - same loss and gradients bit for
+    bit (deterministic kernels), lower peak memory."""
+    cfg = CFG._replace(num_layers=6, max_seq_len=2048)
+    p = O.init_params(cfg)
+    p.update(O.init_lora(cfg, 8))
+    pb, _ = bf16_params(p)
+    tokens, labels = _data(2, 2048)
+    res = {}
+    for ckpt in (False, True):
+        model = build_model(cfg._replace(activation_checkpointing=ckpt), pb, cuda, lora_rank=8)
+        assert model.config.activation_checkpointing == ckpt
+        for n, q in model.named_parameters():
+            q.requires_grad_("lora_" in n or n.endswith("_norm.weight") or n.startswith("tok_embeddings"))
+        torch.cuda.synchronize()
+        torch.cuda.reset_peak_memory_stats()
+        base = torch.cuda.memory_allocated()
+        loss = model(tokens.to(cuda), labels=labels.to(cuda))
+        loss.backward()
+        torch.cuda.synchronize()
+        res[ckpt] = (loss.detach().clone(), {n: q.grad.clone() for n, q in model.named_parameters() if q.grad is not None},
+                     torch.cuda.max_memory_allocated() - base)
+        del model, loss
+    (l0, g0, m0), (l1, g1, m1) = res[False], res[True]
+    assert torch.equal(l0, l1), (l0, l1)
+    assert g0.keys() == g1.keys() and len(g0) > 0
+    for n in g0:
+        assert torch.equal(g0[n], g1[n]), n
+    assert m1 < 0.75 * m0, f"checkpointing must lower peak activation memory: {m1 / 2**20:.0f} MiB vs {m0 / 2**20:.0f} MiB"
+
+
+# ------------------------------------------------------------------------------------------------- A18 DoRA inside the fused blocks
+def test_dora_model_loss_and_grads(cuda):
+    """apply_linear_adapter_(model.layers, "dora") (the scripts' --adapter dora): every linear of the fused attention / MLP blocks
+    is a DoRALinear.  Loss against the reference's golden value (g08_dora_model, fp32) and loss + gradients of m / lora_a / lora_b
+    against the oracle on the same bf16-rounded parameters."""
+    import numpy as np
+    import os
+
+    from modelling import DoRALinear, apply_linear_adapter_
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "g08_dora_model.npz"))
+    p = O.init_params(CFG)
+    p.update(O.init_lora(CFG, 8))
+    p.update(O.init_dora_m(p, CFG))
+    pb, pf = bf16_params(p)
+    tokens, labels = _data(2, 256)
+    train = [k for k in pf if "lora_" in k or k.endswith(".m")]
+    pr = {k: (v.clone().requires_grad_() if k in train else v) for k, v in pf.items()}
+    ref = O.llama_forward(tokens, pr, CFG, labels=labels, lora_scale=2.0)
+    ref.backward()
+    assert abs(ref.item() - float(g["loss"])) < 5e-3, "bf16-rounded parameters move the fp32 golden loss only slightly"
+    model = build_model(CFG, {k: v for k, v in pb.items() if "lora_" not in k and not k.endswith(".m")}, torch.device("cpu"))
+    apply_linear_adapter_(model.layers, "dora", rank=8, alpha=16.0)
+    with torch.no_grad():
+        for name, mod in model.layers.named_modules():
+            if isinstance(mod, DoRALinear):
+                torch.testing.assert_close(mod.m.float(), pf[f"layers.{name}.weight"].norm(dim=1), rtol=2 ** -7, atol=0)  # init = ||W||_row
+                mod.lora_a.copy_(pb[f"layers.{name}.lora_a"])
+                mod.lora_b.copy_(pb[f"layers.{name}.lora_b"])
+                mod.m.copy_(pb[f"layers.{name}.m"])
+    model = model.to(cuda)
+    for n, q in model.named_parameters():
+        q.requires_grad_("lora_" in n or n.endswith(".m"))
+    loss = model(tokens.to(cuda), labels=labels.to(cuda))
+    loss.backward()
+    assert abs(loss.item() - ref.item()) < 3e-3 * max(1.0, abs(ref.item())), (loss.item(), ref.item())
+    for name, q in model.named_parameters():
+        if q.requires_grad:
+            assert q.grad is not None, name
+            _close(q.grad.float().cpu(), pr[name].grad, 0.05, name)
+    for key in ("layers_0_attention_wq_m", "layers_1_feed_forward_w2_m"):  # and the reference's own gradient of m, to bf16 tolerance
+        name = key.replace("layers_0_", "layers.0.").replace("layers_1_", "layers.1.").replace("attention_wq_m", "attention.wq.m").replace("feed_forward_w2_m", "feed_forward.w2.m")
+        _close(dict(model.named_parameters())[name].grad.float().cpu(), torch.from_numpy(g[key]), 0.08, name + " vs reference golden")

@@ -127,6 +127,21 @@ def test_dora():
     torch.testing.assert_close(O.dora_linear(x, w, a, lb, g["m"], 2.0, b), g["y"], atol=1e-5, rtol=1e-5)
 
 
+def test_dora_model():
+    """apply_linear_adapter_(model.layers, "dora") through the whole model: loss and gradients of m / lora_a / lora_b."""
+    g = G("g08_dora_model")
+    params = dict(O.init_params(CFG))
+    params.update({k: v.clone().requires_grad_() for k, v in O.init_lora(CFG, 8).items()})
+    params.update({k: v.clone().requires_grad_() for k, v in O.init_dora_m(params, CFG).items()})
+    tokens, labels = tokens_labels(2, 256)
+    loss = O.llama_forward(tokens, params, CFG, labels=labels, lora_scale=2.0)
+    loss.backward()
+    torch.testing.assert_close(loss.detach(), g["loss"], atol=1e-6, rtol=1e-6)
+    for name in ("layers.0.attention.wq.m", "layers.0.attention.wq.lora_a", "layers.1.feed_forward.w2.m", "layers.1.feed_forward.w1.lora_b",
+                 "layers.0.attention.wv.m"):
+        torch.testing.assert_close(params[name].grad, g[name.replace(".", "_")], atol=1e-7, rtol=3e-4)
+
+
 def test_int8_bit_exact():
     g = G("g09_quant_bf16")
     w8 = O.randn("q_w", (96, 512), 0.05).bfloat16()
