@@ -70,11 +70,7 @@ def cpu_baseline(seq: int, rank: int):
     """Oracle (CPU restatement of the reference) timed on the host cores on a bounded sample of the same workload."""
     from oracle import ref as O
 
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cores = os.cpu_count() or 1
-    cores = max(1, min(cores, 64))  # a 1-GPU box shares its host: use the cores this process may run on
+    cores = max(1, min(_affinity_cores(), 64))  # a 1-GPU box shares its host: use the cores this process may run on
     torch.set_num_threads(cores)
     # sample: ONE of the 32 layers at the full sequence length (so attention's S^2 term is measured, not extrapolated) and the
     # LM head + CE on a quarter of the positions - about 10-30 s of CPU work on a 64-core host
@@ -113,38 +109,56 @@ def cpu_baseline(seq: int, rank: int):
                       f"{t_head:.2f}s; scaled to 32 layers and {seq} positions"}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=4)
-    ap.add_argument("--seq", type=int, default=4096)
-    ap.add_argument("--rank", type=int, default=16)
-    ap.add_argument("--model", default="llama31_8b", choices=["llama31_8b", "tiny"])
-    ap.add_argument("--config", default="text", choices=["text", "int8", "audio", "packed"],
-                    help="text: BASELINE configs[1] (headline); int8: configs[3] per-GPU (INT8 frozen base, dynamic int8 activations, i8 MFMA) ; "
-                         "audio: configs[2] (mel+Conv1D prefix of seq/2 audio tokens + seq/2 text tokens, prefix-LM mask, audio_embed trainable)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a captured hipGraph (single GPU)")
-    args = ap.parse_args()
+def _affinity_cores():
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
-    torch.cuda.set_device(local)
-    device = torch.device("cuda", local)
-    if world > 1 or os.environ.get("LLX_FORCE_DP") == "1":
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", device_id=device, rank=rank, world_size=world)  # "nccl" is RCCL on ROCm
 
+WORKLOAD_TEXT = {
+    "text": "Llama-3.1-8B text-only LoRA r={rank} bf16, seq={S}, 1 sequence per GPU, causal mask, base+LM head frozen (BASELINE.json configs[1]); "
+            "random-init weights at 8B dimensions",
+    "int8": "Llama-3.1-8B INT8 frozen base (dynamic int8 activations, i8 MFMA int8_mm_dequant) + bf16 LoRA r={rank}, seq={S}, 1 sequence per GPU "
+            "(BASELINE.json configs[3] per-GPU workload)",
+    "packed": "Llama-3.1-8B text-only LoRA r={rank} bf16, seq={S} packed from {n_docs} synthetic documents (log-normal lengths), document mask "
+              "(BASELINE.json configs[1], packed variant of SURVEY 8d C2)",
+    "audio": "Llama-3.1-8B + mel/Conv1D audio prefix ({St} audio tokens from {samples} samples) + {St} text tokens, prefix-LM mask, LoRA r={rank} + "
+             "trainable audio_embed (BASELINE.json configs[2])",
+}
+PEAK = {"bf16": (2500.0, "TFLOP/s", "gemm_nt_kernel<EPI, false, 1> (bf16 MFMA GEMM, v_mfma_f32_16x16x32_bf16)"),
+        "i8": (5000.0, "TOP/s", "gemm_nt_kernel<EPI, true, 1> (i8 MFMA GEMM = torchao::int8_mm_dequant, v_mfma_i32_16x16x64_i8)")}
+
+
+def _traffic(args, config: str, kind: str):
+    """HBM bytes per launch from the PMC passes committed under profiles/ FOR THIS workload (model, config, sequence length) and kernel
+    (bench.py cannot run rocprofv3 on itself); None when no such file exists - a number measured on another workload is not a
+    measurement of this one."""
+    if args.model != "llama31_8b":
+        return None
+    try:
+        with open(os.path.join(ROOT, "profiles", f"r02_{config}_s{args.seq}_{kind}_gemm_hbm_traffic.json")) as f:
+            return round(json.load(f)["hbm_bytes_per_launch"])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
+def _roofline(args, config: str, kind: str, st: dict) -> dict:
+    peak, unit, kernel = PEAK[kind]
+    ach = st["flops"] / (st["ms"] * 1e-3) / 1e12
+    return {"bound": "mfma", "achieved": round(ach, 1), "peak": peak, "unit": unit, "frac": round(ach / peak, 4), "traffic": _traffic(args, config, kind),
+            "algorithmic_bytes_per_launch": round(st["alg_bytes"] / max(1, st["launches"])), "kernel": kernel,
+            "launches_per_step": st["launches"], "avg_launch_us": round(st["ms"] * 1e3 / max(1, st["launches"]), 2),
+            "gemm_ms_per_step": round(st["ms"], 2)}
+
+
+def run_workload(args, config: str, device, world: int, rank: int, steps: int, warmup: int) -> dict:
+    """Build the model of one BASELINE configuration, capture its step, time `steps` steps after `warmup`, then trace one eager step with
+    HIP events around every GEMM launch (bf16 and i8 kernels separately).  Returns the raw numbers; main() formats them."""
     from llx import kernels as K
     from llx.dp import GradBuckets
 
-    model, cfg = build_model(args.model, args.seq, args.rank, device, args.config)
+    model, cfg = build_model(args.model, args.seq, args.rank, device, config)
     trainable = [p for p in model.parameters() if p.requires_grad]
     force_dp = os.environ.get("LLX_FORCE_DP") == "1"  # rehearse the N>1 code path (flat buckets + RCCL) on one GPU
     use_graph = not args.no_graph
@@ -158,15 +172,16 @@ def main():
     S = args.seq
     gen = torch.Generator(device=device)
     gen.manual_seed(rank)  # rank-distinct data streams
-    audio_cfg = args.config == "audio"
+    audio_cfg = config == "audio"
     St = S // 2 if audio_cfg else S  # audio: S/2 audio tokens (S/2 * 320 samples) + S/2 text tokens
+    info = {"St": St, "samples": St * 320, "n_docs": 0}
     if audio_cfg:
         from modelling.llama import MaskSpec
 
         audio_buf = (torch.rand(1, St * 320, device=device, generator=gen) - 0.5) * 0.2
         prefix_mask = MaskSpec(prefix_len=torch.tensor([St], device=device, dtype=torch.int32))
     doc_mask = None
-    if args.config == "packed":
+    if config == "packed":
         # packed documents (train_metamathqa.py:51-83): lengths ~ clipped log-normal (median ~190, P99 ~680, max 2318 tokens as the
         # MetaMathQA statistics of SURVEY 8d), packed greedily into the S-token buffer; the unused tail keeps id 0 (packer quirk)
         import numpy as np
@@ -181,7 +196,7 @@ def main():
             doc += 1
             ids_np[pos : pos + n] = doc
             pos += n
-        n_docs = doc
+        info["n_docs"] = doc
         doc_mask = MaskSpec(doc_ids=torch.from_numpy(ids_np).to(device))
 
     def batch():
@@ -259,26 +274,26 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     barrier()
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     t0 = time.perf_counter()
     marks[0].record()
-    for i in range(args.steps):
+    for i in range(steps):
         loss = step()
         marks[i + 1].record()
     barrier()
     elapsed = time.perf_counter() - t0
-    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(steps))
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
 
-    # ---- live roofline of the dominant kernel (the bf16 MFMA GEMM): one more step with HIP events around every launch.
+    # ---- live roofline of the GEMM kernels: one more step with HIP events around every launch (on the launch stream).
     # Every rank runs the step (it contains the gradient exchange); only rank 0 records events.
-    gemm_stats = None
+    gemm_stats = {}
     if rank == 0:
         K.GEMM_TRACE = []
     buckets.zero_grad()
@@ -287,49 +302,102 @@ def main():
     if rank == 0:
         tr = K.GEMM_TRACE
         K.GEMM_TRACE = None
-        tot_ms = sum(s.elapsed_time(e) for s, e, _, _ in tr)
-        tot_fl = sum(f for _, _, f, _ in tr)
-        gemm_stats = {"launches": len(tr), "ms": tot_ms, "flops": tot_fl, "alg_bytes": sum(b for _, _, _, b in tr)}
+        for kind in ("bf16", "i8"):
+            sel = [e for e in tr if e[4] == kind]
+            if sel:
+                gemm_stats[kind] = {"launches": len(sel), "ms": sum(s.elapsed_time(e) for s, e, _, _, _ in sel), "flops": sum(f for _, _, f, _, _ in sel),
+                                    "alg_bytes": sum(b for _, _, _, b, _ in sel)}
+    res = {"config": config, "elapsed": elapsed, "steps": steps, "warmup": warmup, "per_step": per_step, "loss": float(loss.detach()),
+           "launch": launch_mode, "gemm": gemm_stats, "info": info, "S": S}
+    # release the 16 GB of weights + cached images + graph pools before the next workload is built
+    del step, eager_step, run_model, model, optim, buckets, trainable
+    if use_graph:
+        graph = opt_graph = static_loss = None  # noqa: F841
+    import gc
+
+    gc.collect()
+    torch.cuda.empty_cache()
+    return res
+
+
+def _summary(args, r: dict, world: int) -> dict:
+    """Numbers of one workload: whole-job tokens/s, step times, the roofline of its dominant GEMM kernel (+ the i8 kernel's own when it ran)."""
+    ms = r["elapsed"] / r["steps"] * 1e3
+    ps = r["per_step"]
+    d = {"value": round(r["S"] * world * r["steps"] / r["elapsed"], 1), "unit": "tokens/s", "steps": r["steps"], "warmup": r["warmup"],
+         "ms_per_step": round(ms, 2), "p50_step_ms": round(ps[len(ps) // 2], 2), "p10_step_ms": round(ps[len(ps) // 10], 2),
+         "p90_step_ms": round(ps[min(len(ps) - 1, (9 * len(ps)) // 10)], 2), "loss": round(r["loss"], 4), "launch": r["launch"],
+         "workload": (WORKLOAD_TEXT[r["config"]].format(rank=args.rank, S=r["S"], **r["info"]) if args.model == "llama31_8b"
+                      else f"tiny plumbing config seq={r['S']} ({r['config']})")}
+    g = {k: v for k, v in r["gemm"].items() if v["ms"] > 0}
+    if g:
+        dominant = max(g, key=lambda k: g[k]["ms"])  # the kernel the step spends most of its time in
+        d["roofline"] = _roofline(args, r["config"], dominant, g[dominant])
+        if "i8" in g:
+            d["roofline_i8"] = _roofline(args, r["config"], "i8", g["i8"])  # int8_mm_dequant against the 5.0 POP/s i8 MFMA peak
+    return d
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--seq", type=int, default=4096)
+    ap.add_argument("--rank", type=int, default=16)
+    ap.add_argument("--model", default="llama31_8b", choices=["llama31_8b", "tiny"])
+    ap.add_argument("--config", default="text", choices=["text", "int8", "audio", "packed"],
+                    help="text: BASELINE configs[1] (headline); int8: configs[3] per-GPU (INT8 frozen base, dynamic int8 activations, i8 MFMA) ; "
+                         "audio: configs[2] (mel+Conv1D prefix of seq/2 audio tokens + seq/2 text tokens, prefix-LM mask, audio_embed trainable)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a captured hipGraph (single GPU)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the int8 / audio / packed workloads timed after the headline run (N=1, text only)")
+    ap.add_argument("--extra-steps", type=int, default=6, help="timed steps of each extra workload (after 2 warm-up steps)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1 or os.environ.get("LLX_FORCE_DP") == "1":
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", device_id=device, rank=rank, world_size=world)  # "nccl" is RCCL on ROCm
+
+    S = args.seq
+    r = run_workload(args, args.config, device, world, rank, args.steps, args.warmup)
+    extras = {}
+    if world == 1 and args.config == "text" and not args.no_extras and os.environ.get("LLX_FORCE_DP") != "1":
+        # the other single-GPU workloads of BASELINE.json, a few replays each in the same process (reported under "configs")
+        for cfg in ("int8", "audio", "packed"):
+            try:
+                extras[cfg] = _summary(args, run_workload(args, cfg, device, world, rank, args.extra_steps, 2), world)
+            except Exception as exc:  # noqa: BLE001 - an extra workload must not cost the headline line
+                extras[cfg] = {"error": f"{type(exc).__name__}: {exc}"}
+                print(f"[bench] extra workload {cfg} failed: {exc}", file=sys.stderr, flush=True)
 
     if rank == 0:
-        ms_per_step = elapsed / args.steps * 1e3
-        tokens = S * world * args.steps
-        value = tokens / elapsed
+        sm = _summary(args, r, world)
         out = {
             "metric": "train tokens/sec Llama-3.1-8B seq4096 at 1/2/4/8 MI355X; p50 step ms",
-            "value": round(value, 1), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 2),
-            "p50_step_ms": round(per_step[len(per_step) // 2], 2), "p10_step_ms": round(per_step[len(per_step) // 10], 2),
-            "p90_step_ms": round(per_step[min(len(per_step) - 1, (9 * len(per_step)) // 10)], 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": ({"text": f"Llama-3.1-8B text-only LoRA r={args.rank} bf16, seq={S}, 1 sequence per GPU, causal mask, base+LM head frozen "
-                                             "(BASELINE.json configs[1]); random-init weights at 8B dimensions",
-                                     "int8": f"Llama-3.1-8B INT8 frozen base (dynamic int8 activations, i8 MFMA int8_mm_dequant) + bf16 LoRA r={args.rank}, seq={S}, "
-                                             "1 sequence per GPU (BASELINE.json configs[3] per-GPU workload)",
-                                     "packed": f"Llama-3.1-8B text-only LoRA r={args.rank} bf16, seq={S} packed from {n_docs if args.config == 'packed' else 0} synthetic documents "
-                                               "(log-normal lengths), document mask (BASELINE.json configs[1], packed variant of SURVEY 8d C2)",
-                                     "audio": f"Llama-3.1-8B + mel/Conv1D audio prefix ({St} audio tokens from {St * 320} samples) + {St} text tokens, prefix-LM mask, "
-                                              f"LoRA r={args.rank} + trainable audio_embed (BASELINE.json configs[2])"}[args.config]
-                                    if args.model == "llama31_8b" else f"tiny plumbing config seq={S} ({args.config})"),
-                       "global_batch_tokens": S * world, "seq_len": S, "parallelism": f"dp{world}", "loss": round(float(loss.detach()), 4), "launch": launch_mode},
+            "value": sm["value"], "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": sm["ms_per_step"], "p50_step_ms": sm["p50_step_ms"], "p10_step_ms": sm["p10_step_ms"], "p90_step_ms": sm["p90_step_ms"],
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": sm["workload"], "global_batch_tokens": S * world, "seq_len": S, "parallelism": f"dp{world}", "loss": sm["loss"],
+                       "launch": sm["launch"]},
         }
         gf = GF_PER_TOKEN.get(S)
         if gf and args.model == "llama31_8b" and args.config == "text":
-            out["step_mfma_frac"] = round(gf * 1e9 * S / (ms_per_step * 1e-3) / 1e12 / BF16_DENSE_PEAK_TFLOPS, 4)
-        if gemm_stats and gemm_stats["ms"] > 0:
-            ach = gemm_stats["flops"] / (gemm_stats["ms"] * 1e-3) / 1e12
-            traffic = None  # HBM bytes per launch from the PMC passes committed under profiles/ (bench.py cannot run rocprofv3 on itself)
-            try:
-                with open(os.path.join(ROOT, "profiles", "r01_gemm_hbm_traffic.json")) as f:
-                    traffic = round(json.load(f)["hbm_bytes_per_launch"])
-            except (OSError, KeyError, ValueError):
-                pass
-            out["roofline"] = {"bound": "mfma", "achieved": round(ach, 1), "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "frac": round(ach / BF16_DENSE_PEAK_TFLOPS, 4), "traffic": traffic,
-                               "algorithmic_bytes_per_launch": round(gemm_stats["alg_bytes"] / max(1, gemm_stats["launches"])),
-                               "kernel": "gemm_nt_kernel (bf16 MFMA GEMM)",
-                               "launches_per_step": gemm_stats["launches"], "avg_launch_us": round(gemm_stats["ms"] * 1e3 / max(1, gemm_stats["launches"]), 2),
-                               "gemm_ms_per_step": round(gemm_stats["ms"], 2)}
+            out["step_mfma_frac"] = round(gf * 1e9 * S / (sm["ms_per_step"] * 1e-3) / 1e12 / BF16_DENSE_PEAK_TFLOPS, 4)
+        for k in ("roofline", "roofline_i8"):
+            if k in sm:
+                out[k] = sm[k]
+        if extras:
+            out["configs"] = extras
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(S, args.rank)
         result_line = json.dumps(out)

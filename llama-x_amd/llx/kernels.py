@@ -19,7 +19,8 @@ EPI_NONE, EPI_RESIDUAL, EPI_BIAS, EPI_BIAS_GELU, EPI_COLSCALE = 0, 1, 2, 3, 4
 EPI_SWIGLU_BWD = 6  # the product is dh; e = gate|up [M, 2N]; out = dg|du [M, 2N] (dh itself is not stored)
 EPI_SWIGLU_FWD = 7  # b = [W_gate; W_up]; out = gate|up [M, N]; e = OUTPUT h [M, N/2] = silu(g) * u
 SK_PAD = 64
-GEMM_TRACE = None  # bench.py sets this to a list to collect (start_event, end_event, algorithmic_flops) per GEMM launch
+# bench.py sets this to a list to collect (start_event, end_event, algorithmic ops, algorithmic bytes, "bf16" | "i8") per GEMM launch
+GEMM_TRACE = None
 
 
 def _lib():
@@ -76,9 +77,12 @@ def rmsnorm_bwd(dy: Tensor, x: Tensor, w: Tensor, rstd: Tensor, need_dw: bool, d
 
 # ------------------------------------------------------------------------------------------------- gemm
 def gemm_nt(a: Tensor, b: Tensor, *, out: Optional[Tensor] = None, a2: Optional[Tensor] = None, b2: Optional[Tensor] = None,
-            epilogue: int = EPI_NONE, e: Optional[Tensor] = None, rope: Optional[tuple[Tensor, int, int]] = None) -> Tensor:
+            epilogue: int = EPI_NONE, e: Optional[Tensor] = None, rope: Optional[tuple[Tensor, int, int]] = None,
+            k2_eff: Optional[float] = None) -> Tensor:
     """out[M,N] = a[M,K] @ b[N,K]^T (+ a2[M,K2] @ b2[N,K2]^T) with a fused epilogue; bf16, fp32 accumulate.
-    rope = (fp32 table [>= S, 64, 2], S, cols): apply_rope on columns [0, cols) of out in the epilogue (row m = position m % S)."""
+    rope = (fp32 table [>= S, 64, 2], S, cols): apply_rope on columns [0, cols) of out in the epilogue (row m = position m % S).
+    k2_eff: accounting only - the K-extension's true contraction length (LoRA rank; the operands are zero padded to 64 columns and
+    block diagonal for fused groups), used by the GEMM trace so that multiplying zeros is not counted as algorithmic work."""
     _chk_bf16(a, b, a2, b2, e, out)
     assert a.dim() == 2 and b.dim() == 2 and a.shape[1] == b.shape[1], (a.shape, b.shape)
     assert a.stride(1) == 1 and b.stride(1) == 1
@@ -122,7 +126,8 @@ def gemm_nt(a: Tensor, b: Tensor, *, out: Optional[Tensor] = None, a2: Optional[
                                         epilogue, L.ptr(e), lde, L.stream()), "llx_gemm_nt_bf16")
     if ev is not None:
         ev[1].record()
-        GEMM_TRACE.append((ev[0], ev[1], 2.0 * M * N * (K + K2), 2.0 * (M * (K + K2) + N * (K + K2) + M * N * (2 if epilogue == EPI_RESIDUAL else 1))))
+        kk = K + (K2 if k2_eff is None else min(float(k2_eff), K2))
+        GEMM_TRACE.append((ev[0], ev[1], 2.0 * M * N * kk, 2.0 * (M * kk + N * kk + M * N * (2 if epilogue == EPI_RESIDUAL else 1)), "bf16"))
     return out
 
 

@@ -103,7 +103,7 @@ class LinearPlan:
                 raise LlxError("DoRA + GELU epilogue is not supported")
             w = self.weight.detach()
             c, inv = dora_colscale([self], w, self.lora_a.detach(), b2)
-            z = K.gemm_nt(x, w, a2=t, b2=b2)
+            z = K.gemm_nt(x, w, a2=t, b2=b2, k2_eff=self.rank)
             direct = residual is None
             y = K.colscale_bias(z, c, self.bias.detach() if self.bias is not None else None, out=out if direct else None)
             if residual is not None:
@@ -118,7 +118,7 @@ class LinearPlan:
             direct = self.rank == 0 and residual is None
             y = int8_linear_forward(x, self.weight, out=out if direct else None)
             if self.rank > 0:
-                y = K.gemm_nt(t, b2, out=out if residual is None else None, epilogue=K.EPI_RESIDUAL, e=y)
+                y = K.gemm_nt(t, b2, out=out if residual is None else None, epilogue=K.EPI_RESIDUAL, e=y, k2_eff=0)
             if residual is not None:
                 y = K.add(y, residual, out=out)
             return y, t
@@ -126,11 +126,11 @@ class LinearPlan:
         if self.bias is not None:
             if residual is not None:
                 raise LlxError("bias + residual epilogue is not supported")
-            y = K.gemm_nt(x, w, out=out, a2=t, b2=b2, epilogue=K.EPI_BIAS_GELU if gelu else K.EPI_BIAS, e=self.bias.detach())
+            y = K.gemm_nt(x, w, out=out, a2=t, b2=b2, epilogue=K.EPI_BIAS_GELU if gelu else K.EPI_BIAS, e=self.bias.detach(), k2_eff=self.rank)
         elif residual is not None:
-            y = K.gemm_nt(x, w, out=out, a2=t, b2=b2, epilogue=K.EPI_RESIDUAL, e=residual)
+            y = K.gemm_nt(x, w, out=out, a2=t, b2=b2, epilogue=K.EPI_RESIDUAL, e=residual, k2_eff=self.rank)
         else:
-            y = K.gemm_nt(x, w, out=out, a2=t, b2=b2)
+            y = K.gemm_nt(x, w, out=out, a2=t, b2=b2, k2_eff=self.rank)
         return y, t
 
     # ---- backward: grads of tensors() and (optionally) dx (accumulated into dx_out when dx_accum)
@@ -177,9 +177,9 @@ class LinearPlan:
                 g = dy
                 wt = weight_t(self.weight)
             if dx_accum:
-                dx = K.gemm_nt(g, wt, out=dx_out, a2=u, b2=b2, epilogue=K.EPI_RESIDUAL, e=dx_out)
+                dx = K.gemm_nt(g, wt, out=dx_out, a2=u, b2=b2, epilogue=K.EPI_RESIDUAL, e=dx_out, k2_eff=self.rank)
             else:
-                dx = K.gemm_nt(g, wt, out=dx_out, a2=u, b2=b2)
+                dx = K.gemm_nt(g, wt, out=dx_out, a2=u, b2=b2, k2_eff=self.rank)
         return dx, grads
 
 
@@ -241,6 +241,8 @@ class GroupPlan:
                       and all(m.bias is None for m in self.members) and all(m.K == self.K for m in self.members))
         self.int8, self.dynamic = m0.int8, m0.dynamic
         self.scale = next((m.scale for m in self.members if m.rank > 0), 1.0)
+        # true contraction length of the (block-diagonal, zero-padded) LoRA K-extension: forward sum_i N_i r_i / N, dgrad R
+        self.k2_fwd = sum(n * r for n, r in zip(self.Ns, self.ranks)) / self.N
 
     def tensors(self) -> list[Tensor]:
         return [t for m in self.members for t in m.tensors()]
@@ -298,18 +300,18 @@ class GroupPlan:
             # SwiGLU run stand-alone after this group (rope_fusable / swiglu_fusable are False)
             assert swiglu_h is None and rope is None
             c, inv = dora_colscale(self.members, self.w_cat(), a_cat, b2)
-            z = K.gemm_nt(x, self.w_cat(), a2=t[0], b2=b2)
+            z = K.gemm_nt(x, self.w_cat(), a2=t[0], b2=b2, k2_eff=self.k2_fwd)
             K.scale(z, colscale=c, out=out)
             if residual is not None:
                 K.add(out, residual, out=out)
             return (*t, z, c, inv)
         if not self.int8:
             if residual is not None:
-                K.gemm_nt(x, self.w_cat(), out=out, a2=t[0] if t else None, b2=b2, epilogue=K.EPI_RESIDUAL, e=residual)
+                K.gemm_nt(x, self.w_cat(), out=out, a2=t[0] if t else None, b2=b2, epilogue=K.EPI_RESIDUAL, e=residual, k2_eff=self.k2_fwd)
             elif swiglu_h is not None:  # gate|up group: h = silu(g) * u leaves the same GEMM (g and u are stored as usual)
-                K.gemm_nt(x, self.w_cat(), out=out, a2=t[0] if t else None, b2=b2, epilogue=K.EPI_SWIGLU_FWD, e=swiglu_h)
+                K.gemm_nt(x, self.w_cat(), out=out, a2=t[0] if t else None, b2=b2, epilogue=K.EPI_SWIGLU_FWD, e=swiglu_h, k2_eff=self.k2_fwd)
             else:
-                K.gemm_nt(x, self.w_cat(), out=out, a2=t[0] if t else None, b2=b2, rope=rope)
+                K.gemm_nt(x, self.w_cat(), out=out, a2=t[0] if t else None, b2=b2, rope=rope, k2_eff=self.k2_fwd)
             return t
         if self.dynamic:
             from subclasses.int8 import quantize_int8_rowwise
@@ -330,7 +332,7 @@ class GroupPlan:
             y0 = K.gemm_nt(x, self.w_cat(), out=out if direct else None, epilogue=K.EPI_COLSCALE, e=self.scale_cat())
         # (x @ W8^T) * scale is rounded to bf16 first (subclasses/int8.py:118); adapter and residual are added after
         if self.R > 0:
-            y0 = K.gemm_nt(t[0], b2, out=out if residual is None else None, epilogue=K.EPI_RESIDUAL, e=y0)
+            y0 = K.gemm_nt(t[0], b2, out=out if residual is None else None, epilogue=K.EPI_RESIDUAL, e=y0, k2_eff=0)
         if residual is not None:
             K.add(y0, residual, out=out)
         return t
@@ -431,10 +433,30 @@ class GroupPlan:
         if need_dx:
             g = K.scale(dy, colscale=self.scale_cat()) if self.int8 else dy  # (g * scale) rounded (subclasses/int8.py:127)
             if swiglu is not None:
-                dx = K.gemm_nt(g, self.wt_cat(), out=swiglu[1], a2=u, b2=a2t if self.R > 0 else None, epilogue=K.EPI_SWIGLU_BWD, e=swiglu[0])
+                dx = K.gemm_nt(g, self.wt_cat(), out=swiglu[1], a2=u, b2=a2t if self.R > 0 else None, epilogue=K.EPI_SWIGLU_BWD, e=swiglu[0], k2_eff=self.R)
             else:
-                dx = K.gemm_nt(g, self.wt_cat(), out=dx_out, a2=u, b2=a2t if self.R > 0 else None)
+                dx = K.gemm_nt(g, self.wt_cat(), out=dx_out, a2=u, b2=a2t if self.R > 0 else None, k2_eff=self.R)
         return dx, grads
+
+
+def _enc(o, flat: list):
+    # module-level on purpose: a recursive CLOSURE over `flat` would be a reference cycle (function <-> its own cell) that keeps every
+    # saved activation alive until the cyclic GC happens to run - exactly the memory activation checkpointing is there to release
+    if isinstance(o, Tensor):
+        flat.append(o)
+        return ("t", len(flat) - 1)
+    if isinstance(o, (tuple, list)):
+        return ("l", [_enc(x, flat) for x in o])
+    return ("c", o)
+
+
+def _dec(sp, flat):
+    kind, v = sp
+    if kind == "t":
+        return flat[v]
+    if kind == "l":
+        return tuple(_dec(x, flat) for x in v)
+    return v
 
 
 def _save(ctx, *objs) -> None:
@@ -442,31 +464,13 @@ def _save(ctx, *objs) -> None:
     (non-reentrant ``checkpoint`` at modelling/llama.py, CPU offload) then see the activations and can drop / recompute them,
     and autograd's in-place version checks cover them.  Only the nesting structure stays on ``ctx``."""
     flat: list[Tensor] = []
-
-    def enc(o):
-        if isinstance(o, Tensor):
-            flat.append(o)
-            return ("t", len(flat) - 1)
-        if isinstance(o, (tuple, list)):
-            return ("l", [enc(x) for x in o])
-        return ("c", o)
-
-    ctx._llx_spec = [enc(o) for o in objs]
+    ctx._llx_spec = [_enc(o, flat) for o in objs]
     ctx.save_for_backward(*flat)
 
 
 def _load(ctx) -> list:
     flat = ctx.saved_tensors
-
-    def dec(sp):
-        kind, v = sp
-        if kind == "t":
-            return flat[v]
-        if kind == "l":
-            return tuple(dec(x) for x in v)
-        return v
-
-    return [dec(sp) for sp in ctx._llx_spec]
+    return [_dec(sp, flat) for sp in ctx._llx_spec]
 
 
 def _plans_tensors(plans: Sequence[LinearPlan]) -> tuple[list[Tensor], list[int]]:

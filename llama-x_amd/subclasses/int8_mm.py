@@ -31,6 +31,23 @@ def _meta(A, B, A_scale_rowwise, B_scale_colwise):
 
 def _launch(A: Tensor, Bt: Tensor, a_scale: Tensor, b_scale: Tensor, out: Tensor | None = None, a2: Tensor | None = None,
             b2: Tensor | None = None, epilogue: int = 0, e: Tensor | None = None, rope: tuple | None = None) -> Tensor:
+    from llx import kernels as K
+
+    if K.GEMM_TRACE is None:
+        return _launch_impl(A, Bt, a_scale, b_scale, out, a2, b2, epilogue, e, rope)
+    ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+    ev[0].record()
+    res = _launch_impl(A, Bt, a_scale, b_scale, out, a2, b2, epilogue, e, rope)
+    ev[1].record()
+    M, Kd = A.shape
+    N = Bt.shape[0]
+    # algorithmic work of the i8 kernel: the int8 product only (the bf16 LoRA extension riding in the same launch is not counted)
+    K.GEMM_TRACE.append((ev[0], ev[1], 2.0 * M * N * Kd, 1.0 * (M * Kd + N * Kd) + 2.0 * M * N * (2 if epilogue == 1 else 1), "i8"))
+    return res
+
+
+def _launch_impl(A: Tensor, Bt: Tensor, a_scale: Tensor, b_scale: Tensor, out: Tensor | None = None, a2: Tensor | None = None,
+                 b2: Tensor | None = None, epilogue: int = 0, e: Tensor | None = None, rope: tuple | None = None) -> Tensor:
     """A [M,K] int8 rows, Bt [N,K] int8 rows (= B^T), scales bf16 -> out [M,N] bf16.
     a2 [M,K2], b2 [N,K2] (bf16, K2 % 64 == 0): a LoRA term a2 @ b2^T added on top of the dequantised product in the same launch;
     epilogue 1 (+ e [M,N]), 7 (SwiGLU forward, e = OUTPUT h [M,N/2]) or rope = (table, S, cols) as in llx.kernels.gemm_nt."""

@@ -28,5 +28,9 @@ def test_tiny_bench_line(cuda, extra):
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 2 and d["higher_is_better"] is True and d["scaling"] == "weak"
     assert d["value"] > 0 and abs(d["value"] - 512 / (d["ms_per_step"] * 1e-3)) < 0.02 * d["value"]
     r = d["roofline"]
-    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert r["bound"] == "mfma" and r["unit"] in ("TFLOP/s", "TOP/s") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert r["unit"] == "TFLOP/s" or "--config" in extra and "int8" in extra  # only the int8 workload may be dominated by the i8 kernel
+    if "int8" in extra:
+        assert d["roofline_i8"]["peak"] == 5000.0 and d["roofline_i8"]["unit"] == "TOP/s" and d["roofline_i8"]["traffic"] is None
+    assert r["traffic"] is None  # no PMC file exists for a tiny plumbing workload
     assert "workload" in d["config"] and "model" not in d["config"]
