@@ -386,17 +386,21 @@ class GroupPlan:
             cnt = len(m.tensors())
             need.append([next(ni) for _ in range(cnt)])
         ia = -3 if self.dora else -2  # per-member needs end with (..., lora_a, lora_b[, m])
+        dy_out = dy
+        z = inv = None
         if self.dora:  # out = z * c: d m = colsum(dy * z) / norm; everything upstream sees dz = dy * c
             t, bT, a2t, z, c, inv = saved
-            if any(nd[-1] for nd in need):
-                gM = K.colsum_mul(dy, z, inv)
-            dy = K.scale(dy, colscale=c)
+            dy = K.scale(dy_out, colscale=c)
         else:
             t, bT, a2t = saved if saved is not None else (None, None, None)
         u = gA = gBt = None
         gB_views: Optional[list[Optional[Tensor]]] = None
         if self.R > 0:
             u = K.skinny_nt(dy, bT, self._kranges())  # [M,64]: column block i = dy_i @ B_i
+        # parameter gradients
+        if self.dora and any(nd[-1] for nd in need):
+            gM = K.colsum_mul(dy_out, z, inv)
+        if self.R > 0:
             if any(nd[ia] for nd in need):
                 gA = torch.empty(self.R, self.K, device=dy.device, dtype=BF16)
                 K.skinny_tn(u, x, self.R, self.scale, gA, transpose_out=False)
@@ -406,9 +410,9 @@ class GroupPlan:
                     flat = torch.empty(sum((b - a) * (d - c) for a, b, c, d in segs), device=dy.device, dtype=BF16)
                     K.skinny_tn(t, dy, self.R, self.scale, flat, transpose_out=True, segs=segs)
                     gB_views, off = [], 0
-                    for m_, (a, b, c, d) in zip([m for m in self.members if m.rank > 0], segs):
-                        gB_views.append(flat[off : off + (b - a) * (d - c)].view(b - a, d - c))
-                        off += (b - a) * (d - c)
+                    for m_, (a, b, c_, d) in zip([m for m in self.members if m.rank > 0], segs):
+                        gB_views.append(flat[off : off + (b - a) * (d - c_)].view(b - a, d - c_))
+                        off += (b - a) * (d - c_)
                 else:
                     gBt = torch.empty(self.N, self.R, device=dy.device, dtype=BF16)
                     K.skinny_tn(t, dy, self.R, self.scale, gBt, transpose_out=True)
