@@ -163,10 +163,6 @@ def run_workload(args, config: str, device, world: int, rank: int, steps: int, w
     force_dp = os.environ.get("LLX_FORCE_DP") == "1"  # rehearse the N>1 code path (flat buckets + RCCL) on one GPU
     use_graph = not args.no_graph
     dp = world > 1 or force_dp
-    # N>1: forward+backward replay from a hipGraph into flat gradient buckets, then ONE exchange of the 84 MB of trainable
-    # gradients (latency-bound on xGMI: ~1 ms) and the optimizer; --no-graph = eager launches with the exchange overlapped
-    # with backward from autograd hooks.  N=1: the optimizer step is captured too.
-    buckets = GradBuckets(model, n_buckets=4, force=force_dp, overlap=not use_graph)
     optim = torch.optim.AdamW(trainable, lr=1e-4, weight_decay=0.0, fused=True, capturable=use_graph)
 
     S = args.seq
@@ -175,12 +171,12 @@ def run_workload(args, config: str, device, world: int, rank: int, steps: int, w
     audio_cfg = config == "audio"
     St = S // 2 if audio_cfg else S  # audio: S/2 audio tokens (S/2 * 320 samples) + S/2 text tokens
     info = {"St": St, "samples": St * 320, "n_docs": 0}
+    audio_buf = mask = None
     if audio_cfg:
         from modelling.llama import MaskSpec
 
         audio_buf = (torch.rand(1, St * 320, device=device, generator=gen) - 0.5) * 0.2
-        prefix_mask = MaskSpec(prefix_len=torch.tensor([St], device=device, dtype=torch.int32))
-    doc_mask = None
+        mask = MaskSpec(prefix_len=torch.tensor([St], device=device, dtype=torch.int32))
     if config == "packed":
         # packed documents (train_metamathqa.py:51-83): lengths ~ clipped log-normal (median ~190, P99 ~680, max 2318 tokens as the
         # MetaMathQA statistics of SURVEY 8d), packed greedily into the S-token buffer; the unused tail keeps id 0 (packer quirk)
@@ -197,7 +193,7 @@ def run_workload(args, config: str, device, world: int, rank: int, steps: int, w
             ids_np[pos : pos + n] = doc
             pos += n
         info["n_docs"] = doc
-        doc_mask = MaskSpec(doc_ids=torch.from_numpy(ids_np).to(device))
+        mask = MaskSpec(doc_ids=torch.from_numpy(ids_np).to(device))
 
     def batch():
         ids = torch.randint(0, cfg.vocab_size, (1, St), device=device, generator=gen)
@@ -208,66 +204,81 @@ def run_workload(args, config: str, device, world: int, rank: int, steps: int, w
 
     def run_model(ids, labels):
         if audio_cfg:
-            return model(audio_buf, ids, labels=labels, block_mask=prefix_mask)
-        if doc_mask is not None:
-            return model(ids, labels=labels, block_mask=doc_mask)
-        return model(ids, labels=labels)
+            return model(audio_buf, ids, labels=labels, block_mask=mask)
+        return model(ids, labels=labels, block_mask=mask)
 
-    def eager_step():
-        ids, labels = batch()
-        loss = run_model(ids, labels)
-        loss.backward()
-        buckets.finish()
-        optim.step()
-        buckets.zero_grad()
-        return loss
+    ids_buf, labels_buf = batch()
+    graph = opt_graph = static_loss = stepper = None
+    if dp:
+        # N > 1: forward / backward cut into 4 stages of 8 layers (llx.dp.StagedStep): the RCCL all-reduce of a stage's flat gradient
+        # bucket runs under the backward of the next stage - from hipGraphs (one per stage) or eagerly (--no-graph)
+        from llx.dp import StagedStep, llama_stages
 
-    step = eager_step
-    launch_mode = "eager"
-    if use_graph:
-        try:
-            ids_buf, labels_buf = batch()
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                for _ in range(2):  # warm caches (fused / transposed weight images, LDS attributes) outside the capture
-                    buckets.zero_grad()
-                    run_model(ids_buf, labels_buf).backward()
-                    buckets.finish()
-                    optim.step()
-            torch.cuda.current_stream().wait_stream(side)
-            buckets.zero_grad()
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, capture_error_mode="thread_local"):  # the RCCL watchdog thread may poll events meanwhile
-                if dp:
-                    buckets.zero_grad()  # captured memset of the flat buckets (param.grad are views into them)
-                static_loss = run_model(ids_buf, labels_buf)
-                static_loss.backward()
-                if not dp:
-                    optim.step()
-            opt_graph = None
-            if dp:  # the optimizer step replays from its own graph after the gradient exchange
-                opt_graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(opt_graph, capture_error_mode="thread_local"):
-                    optim.step()
+        stages, stage_params = llama_stages(model, 4, labels=labels_buf, block_mask=mask, audio=audio_buf)
+        stepper = StagedStep(model, stages, stage_params, optim, graph=use_graph, force=force_dp)
+        buckets = stepper.buckets
+
+        def eager_step():
+            ids, labels = batch()
+            ids_buf.copy_(ids)
+            labels_buf.copy_(labels)
+            return stepper._eager((ids_buf,))
+
+        step = eager_step
+        launch_mode = "eager, 4 backward stages, RCCL all-reduce of stage k under the backward of stage k-1"
+        if use_graph:
+            stepper.capture(ids_buf)
 
             def step():
                 ids, labels = batch()
                 ids_buf.copy_(ids)
                 labels_buf.copy_(labels)
-                graph.replay()
-                if dp:
-                    buckets.finish()  # bucketed RCCL all-reduce of the flat gradient buffers
-                    opt_graph.replay()
-                return static_loss
+                return stepper(ids_buf)
 
-            launch_mode = "hipGraph replay (fwd+bwd" + ("+AdamW)" if not dp else "), RCCL all-reduce, hipGraph replay (AdamW)")
-        except Exception as exc:  # noqa: BLE001 - a capture problem must not cost the measurement: fall back to eager launches
-            print(f"[bench] graph capture failed ({type(exc).__name__}: {exc}); running eagerly", file=sys.stderr, flush=True)
-            torch.cuda.synchronize()
-            buckets = GradBuckets(model, n_buckets=4, force=force_dp, overlap=True)
-            optim = torch.optim.AdamW(trainable, lr=1e-4, weight_decay=0.0, fused=True)
-            step = eager_step
+            launch_mode = "hipGraph replay per stage (fwd | 4 x bwd | AdamW), RCCL all-reduce of stage k under the backward of stage k-1"
+    else:
+        buckets = GradBuckets(model, n_buckets=4, force=False, overlap=False)  # single replica: inactive, .grad stays with autograd
+
+        def eager_step():
+            ids, labels = batch()
+            loss = run_model(ids, labels)
+            loss.backward()
+            optim.step()
+            buckets.zero_grad()
+            return loss
+
+        step = eager_step
+        launch_mode = "eager"
+        if use_graph:
+            try:
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    for _ in range(2):  # warm caches (fused / transposed weight images, LDS attributes) outside the capture
+                        buckets.zero_grad()
+                        run_model(ids_buf, labels_buf).backward()
+                        optim.step()
+                torch.cuda.current_stream().wait_stream(side)
+                buckets.zero_grad()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    static_loss = run_model(ids_buf, labels_buf)
+                    static_loss.backward()
+                    optim.step()
+
+                def step():
+                    ids, labels = batch()
+                    ids_buf.copy_(ids)
+                    labels_buf.copy_(labels)
+                    graph.replay()
+                    return static_loss
+
+                launch_mode = "hipGraph replay (fwd+bwd+AdamW)"
+            except Exception as exc:  # noqa: BLE001 - a capture problem must not cost the measurement: fall back to eager launches
+                print(f"[bench] graph capture failed ({type(exc).__name__}: {exc}); running eagerly", file=sys.stderr, flush=True)
+                torch.cuda.synchronize()
+                optim = torch.optim.AdamW(trainable, lr=1e-4, weight_decay=0.0, fused=True)
+                step = eager_step
 
     def barrier():
         if world > 1:
@@ -296,7 +307,8 @@ def run_workload(args, config: str, device, world: int, rank: int, steps: int, w
     gemm_stats = {}
     if rank == 0:
         K.GEMM_TRACE = []
-    buckets.zero_grad()
+    if not dp:
+        buckets.zero_grad()
     eager_step()  # traced eagerly (events between launches), same kernels and shapes as the timed steps
     torch.cuda.synchronize()
     if rank == 0:
@@ -311,8 +323,7 @@ def run_workload(args, config: str, device, world: int, rank: int, steps: int, w
            "launch": launch_mode, "gemm": gemm_stats, "info": info, "S": S}
     # release the 16 GB of weights + cached images + graph pools before the next workload is built
     del step, eager_step, run_model, model, optim, buckets, trainable
-    if use_graph:
-        graph = opt_graph = static_loss = None  # noqa: F841
+    graph = opt_graph = static_loss = stepper = None  # noqa: F841
     import gc
 
     gc.collect()

@@ -15,10 +15,12 @@ from torch import nn
 
 
 class GradBuckets:
-    def __init__(self, model: nn.Module, n_buckets: int = 4, process_group=None, force: bool = False, overlap: bool = True):
+    def __init__(self, model: nn.Module, n_buckets: int = 4, process_group=None, force: bool = False, overlap: bool = True,
+                 groups: "list[list[nn.Parameter]] | None" = None):
         """force: build the flat buckets even for a single replica (tests / rehearsal of the N>1 path on one GPU).
-        overlap: launch each bucket's all-reduce from backward hooks; False = exchange everything in finish()
-        (used when forward+backward replay from a captured hipGraph, where hooks do not run)."""
+        overlap: launch each bucket's all-reduce from backward hooks; False = exchange everything in finish() or bucket by bucket
+        through launch() (used when forward+backward replay from captured hipGraphs, where hooks do not run).
+        groups: explicit bucket contents in exchange order (StagedStep: one bucket per backward stage) instead of equal-size buckets."""
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.active = self.world > 1 or force
@@ -27,21 +29,33 @@ class GradBuckets:
         if not self.active:
             # single replica: nothing to exchange - leave .grad to autograd (no flat views, no accumulate-add kernels)
             self.buckets, self._handles, self._hooks, self.sync_enabled, self.hook_launches = [], [], [], True, 0
+            self.group_of_bucket = []
             return
-        # backward produces gradients roughly in reverse registration order: bucket 0 = last layers
-        params = list(reversed(params))
-        total = sum(p.numel() for p in params)
-        target = (total + n_buckets - 1) // max(1, n_buckets)
         self.buckets: list[dict] = []
-        cur, cur_n = [], 0
-        for p in params:
-            if cur and cur_n + p.numel() > target and len(self.buckets) < n_buckets - 1:
+        self.group_of_bucket: list[int] = []
+        if groups is not None:
+            seen = {id(p) for g in groups for p in g}
+            assert seen == {id(p) for p in params}, "groups must cover exactly the trainable parameters"
+            for g in groups:
+                by_dtype: dict = {}
+                for p in g:
+                    by_dtype.setdefault(p.dtype, []).append(p)
+                self.buckets += [self._make(ps) for ps in by_dtype.values()]
+            self.group_of_bucket = [gi for gi, g in enumerate(groups) for _ in {p.dtype for p in g}]
+        else:
+            # backward produces gradients roughly in reverse registration order: bucket 0 = last layers
+            params = list(reversed(params))
+            total = sum(p.numel() for p in params)
+            target = (total + n_buckets - 1) // max(1, n_buckets)
+            cur, cur_n = [], 0
+            for p in params:
+                if cur and (cur_n + p.numel() > target or p.dtype != cur[0].dtype) and len(self.buckets) < n_buckets - 1:
+                    self.buckets.append(self._make(cur))
+                    cur, cur_n = [], 0
+                cur.append(p)
+                cur_n += p.numel()
+            if cur:
                 self.buckets.append(self._make(cur))
-                cur, cur_n = [], 0
-            cur.append(p)
-            cur_n += p.numel()
-        if cur:
-            self.buckets.append(self._make(cur))
         self._handles = []
         self._hooks = []
         self.hook_launches = 0  # all-reduces started from backward hooks (i.e. overlapped with the rest of backward)
@@ -73,12 +87,27 @@ class GradBuckets:
 
         return hook
 
+    def prescale(self, b):
+        """flat /= world (sum of means = mean of sums, keeps bf16 range).  Split from the exchange so that it can be captured at the
+        end of a backward stage's hipGraph."""
+        if self.world > 1 and not b.get("scaled"):
+            b["flat"].div_(self.world)
+        b["scaled"] = True
+
     def _launch(self, b):
         b["launched"] = True
-        if self.world > 1:
-            b["flat"].div_(self.world)  # pre-scale: sum of means = mean of sums, keeps bf16 range
+        self.prescale(b)
         if dist.is_initialized():
             self._handles.append(dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+
+    def launch_group(self, gi: int):
+        """Start the exchange of every bucket of group `gi` now (asynchronous: RCCL's stream waits for the current stream's tail,
+        the caller goes on queueing the next backward stage)."""
+        if not (self.active and self.sync_enabled):
+            return
+        for b, g in zip(self.buckets, self.group_of_bucket):
+            if g == gi and not b.get("launched"):
+                self._launch(b)
 
     def finish(self):
         """Call after backward, before clip / optimizer.step: exchanges whatever the hooks have not launched yet
@@ -93,6 +122,7 @@ class GradBuckets:
         for b in self.buckets:
             b["pending"] = len(b["params"])
             b["launched"] = False
+            b["scaled"] = False
 
     def zero_grad(self):
         """Keep the views, zero the storage (optimizer.zero_grad(set_to_none=True) would drop the views)."""
@@ -102,3 +132,144 @@ class GradBuckets:
             return
         for b in self.buckets:
             b["flat"].zero_()
+
+
+class StagedStep:
+    """Forward / backward cut into stages so that the gradient exchange of stage k runs under the backward of stage k-1 even when
+    the kernels replay from hipGraphs (autograd hooks do not run in a replay, and an all-reduce issued after ONE whole-step graph
+    overlaps with nothing).
+
+        stages[0](*inputs) -> h0 ; stages[i](h_{i-1}) -> h_i ; stages[-1] returns the loss
+        stage_params[i]: the trainable parameters whose gradients stage i's backward completes
+
+    Activations are detached at the stage boundaries; backward runs last stage first, and as soon as stage i's backward is queued its
+    bucket (one flat buffer per stage and dtype: GradBuckets(groups=...)) is pre-scaled and handed to RCCL, whose stream waits for
+    that point only - the next stage's backward is queued right behind it on the compute stream.  With ``graph=True`` every piece
+    (forward of all stages; backward of each stage incl. the pre-scale; optimizer step) is captured once into its own hipGraph
+    sharing one memory pool, and a step is  replay(F), [replay(B_i), all_reduce_i]..., wait, replay(optimizer).
+    Gradients are bit-identical to the un-staged step (same kernels, same order of accumulation)."""
+
+    def __init__(self, model: nn.Module, stages, stage_params, optim, *, graph: bool = True, process_group=None, force: bool = False):
+        self.stages, self.optim, self.use_graph = list(stages), optim, graph
+        groups = [list(ps) for ps in reversed(list(stage_params))]  # exchange order = backward order
+        self.buckets = GradBuckets(model, groups=groups, process_group=process_group, force=force, overlap=False)
+        self.n = len(self.stages)
+        self._graphs = None
+
+    # ---- one eager pass: returns (loss, boundary tensors) - used for warm-up, for capture and as the eager step
+    def _forward(self, inputs):
+        self._ins, self._outs = [], []
+        h = self.stages[0](*inputs)
+        self._outs.append(h)
+        for st in self.stages[1:]:
+            hin = h.detach().requires_grad_(h.requires_grad)
+            self._ins.append(hin)
+            h = st(hin)
+            self._outs.append(h)
+        return h
+
+    def _backward_stage(self, i: int):
+        out = self._outs[i]
+        if i == self.n - 1:
+            out.backward()
+        elif out.requires_grad:
+            out.backward(self._ins[i].grad)
+        if self.buckets.active:
+            for b, g in zip(self.buckets.buckets, self.buckets.group_of_bucket):
+                if g == self.n - 1 - i:
+                    self.buckets.prescale(b)
+
+    def _eager(self, inputs):
+        self.buckets.zero_grad()
+        loss = self._forward(inputs)
+        for i in reversed(range(self.n)):
+            self._backward_stage(i)
+            self.buckets.launch_group(self.n - 1 - i)
+        self.buckets.finish()
+        self.optim.step()
+        return loss.detach()
+
+    def capture(self, *static_inputs):
+        """Warm up (2 eager steps on a side stream), then capture the forward, every backward stage and the optimizer."""
+        if not self.use_graph:
+            return
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                self._eager(static_inputs)
+        torch.cuda.current_stream().wait_stream(side)
+        kw = dict(capture_error_mode="thread_local")  # the RCCL watchdog thread may poll events meanwhile
+        gf = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gf, **kw):
+            self.buckets.zero_grad()  # captured memset of the flat buckets
+            self._loss = self._forward(static_inputs)
+        pool = gf.pool()
+        gb = []
+        for i in reversed(range(self.n)):
+            for b in self.buckets.buckets:
+                b["scaled"] = False
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=pool, **kw):
+                self._backward_stage(i)
+            gb.append(g)
+        go = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(go, pool=pool, **kw):
+            self.optim.step()
+        self._graphs = (gf, gb, go)
+
+    def __call__(self, *inputs):
+        """One optimizer step.  With graphs the inputs must already sit in the static tensors given to capture()."""
+        if self._graphs is None:
+            return self._eager(inputs)
+        gf, gb, go = self._graphs
+        gf.replay()
+        for k, g in enumerate(gb):
+            g.replay()
+            for b, gi in zip(self.buckets.buckets, self.buckets.group_of_bucket):
+                if gi == k:
+                    b["scaled"] = True  # the replayed stage graph has pre-scaled this bucket
+            self.buckets.launch_group(k)
+        self.buckets.finish()
+        go.replay()
+        return self._loss
+
+
+def llama_stages(model, n_stages: int, *, labels, block_mask=None, audio=None):
+    """(stages, stage_params) for StagedStep over a modelling.Llama / LlamaAudio: contiguous runs of layers; the first stage also owns
+    the embeddings (and the audio front end), the last one the final norm, the LM head and the loss."""
+    L = len(model.layers)
+    n_stages = max(1, min(n_stages, L))
+    bounds = [round(i * L / n_stages) for i in range(n_stages + 1)]
+    state = {}
+
+    def first(tokens):
+        x, n_drop = model._embed(tokens, audio) if audio is not None else model._embed(tokens)
+        state["rope"], state["drop"] = model.rope[: x.shape[1]], n_drop
+        x = model._run_layers(x, state["rope"], bounds[0], bounds[1], block_mask=block_mask)
+        return head(x) if n_stages == 1 else x
+
+    def head(x):
+        if state["drop"]:
+            x = x[:, state["drop"] :]
+        return model._head(x, labels)
+
+    def middle(lo, hi, last):
+        def run(x):
+            x = model._run_layers(x, state["rope"], lo, hi, block_mask=block_mask)
+            return head(x) if last else x
+
+        return run
+
+    stages = [first] + [middle(bounds[i], bounds[i + 1], i == n_stages - 1) for i in range(1, n_stages)]
+    layer_of = {id(p): li for li, layer in enumerate(model.layers) for p in layer.parameters()}
+    stage_params = [[] for _ in range(n_stages)]
+    for name, p in model.named_parameters():
+        if not p.requires_grad:
+            continue
+        if id(p) in layer_of:
+            si = next(i for i in range(n_stages) if bounds[i] <= layer_of[id(p)] < bounds[i + 1])
+        else:
+            si = n_stages - 1 if name.startswith(("norm.", "output.")) else 0
+        stage_params[si].append(p)
+    return stages, stage_params

@@ -41,16 +41,16 @@ class LlamaAudio(Llama):
         super().build_cache(inference)
         self.melspec = audio_ops.MelSpectrogram(**self.audio_config._asdict(), norm="slaney", mel_scale="slaney")
 
+    def _embed(self, tokens: Tensor, audio: Tensor | None = None) -> tuple[Tensor, int]:
+        if audio is None:
+            return self.tok_embeddings(tokens), 0
+        # [audio tokens ; text tokens] are produced into one sequence buffer (reference: cat at audio.py:63)
+        return audio_ops.audio_prefix_and_embed(self, audio, tokens)
+
     def forward(self, audio: Tensor | None, tokens: Tensor, *, input_pos: Tensor | None = None, labels: Tensor | None = None,
                 block_mask=None) -> Tensor:
         mask = self.causal_mask[None, None, input_pos] if input_pos is not None else None  # inference path (generate)
-        B, St = tokens.shape
-        n_audio = 0
-        if audio is None:
-            x = self.tok_embeddings(tokens)
-        else:
-            # [audio tokens ; text tokens] are produced into one sequence buffer (reference: cat at audio.py:63)
-            x, n_audio = audio_ops.audio_prefix_and_embed(self, audio, tokens)
+        x, n_audio = self._embed(tokens, audio)
         rope = self.rope[: x.shape[1]]
         x = self._run_layers(x, rope, mask=mask, input_pos=input_pos, block_mask=block_mask)
         if n_audio:

@@ -248,8 +248,8 @@ class Llama(nn.Module):
             L = self.config.max_seq_len
             self.register_buffer("causal_mask", torch.tril(torch.ones(L, L, dtype=torch.bool)), persistent=False)
 
-    def _run_layers(self, x: Tensor, rope: Tensor, **kw) -> Tensor:
-        for layer in self.layers:
+    def _run_layers(self, x: Tensor, rope: Tensor, lo: int = 0, hi: int | None = None, **kw) -> Tensor:
+        for layer in self.layers[lo:hi]:
             if self.config.activation_checkpointing:
                 x = checkpoint(layer, x, rope, use_reentrant=False, **kw)
             else:
@@ -262,9 +262,13 @@ class Llama(nn.Module):
         plan = ops.LinearPlan(self.output)
         return ops.HeadLossFn.apply(x, self.norm.weight, labels, self.norm.eps, plan, *plan.tensors())
 
+    def _embed(self, x: Tensor) -> tuple[Tensor, int]:
+        """(hidden states [B, S, D], number of leading positions that are dropped before the head)."""
+        return self.tok_embeddings(x), 0
+
     def forward(self, x: Tensor, *, input_pos: Tensor | None = None, block_mask=None, labels: Tensor | None = None) -> Tensor:
         mask = self.causal_mask[None, None, input_pos] if input_pos is not None else None  # inference path (generate)
-        x = self.tok_embeddings(x)
+        x, _ = self._embed(x)
         rope = self.rope[: x.shape[1]]
         x = self._run_layers(x, rope, mask=mask, input_pos=input_pos, block_mask=block_mask)
         return self._head(x, labels)

@@ -84,6 +84,29 @@ def _worker(rank, world, port, q):
         ok4 = launched == len(tr.buckets.buckets) and all(
             torch.allclose(seen[n], dict(ref_model.named_parameters())[n].grad, atol=1e-5) for n in seen)
         ok3 = ok3 and ok4
+    # step 5: StagedStep (eager on CPU): forward / backward in stages with detached boundaries, one bucket per stage exchanged as soon
+    # as the stage's backward is done; averaged gradients equal the single-process reference and the optimizer sees them
+    from llx.dp import StagedStep
+
+    m4 = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.Tanh(), torch.nn.Linear(16, 4), torch.nn.Linear(4, 1))
+    m4.load_state_dict(model.state_dict())
+    m4[2].bias.requires_grad_(False)
+    stages = [lambda xx: m4[1](m4[0](xx)), lambda h: m4[2](h), lambda h: m4[3](h).sum()]
+    sparams = [list(m4[0].parameters()), [m4[2].weight], list(m4[3].parameters())]
+    opt4 = torch.optim.SGD([p for p in m4.parameters() if p.requires_grad], lr=0.0)
+    seen4 = {}
+    opt4.register_step_pre_hook(lambda o, a, k: seen4.update({n: p.grad.clone() for n, p in m4.named_parameters() if p.requires_grad}))
+    st4 = StagedStep(m4, stages, sparams, opt4, graph=False)
+    order = []
+    orig_launch = st4.buckets._launch
+    st4.buckets._launch = lambda b: (order.append(st4.buckets.buckets.index(b)), orig_launch(b))[1]
+    loss4 = st4(x)
+    ref_model.zero_grad()
+    (ref_model(data).sum() / world).backward()
+    ok5 = order == [0, 1, 2] and len(st4.buckets.buckets) == 3 and all(
+        torch.allclose(seen4[n], dict(ref_model.named_parameters())[n].grad, atol=1e-6) for n in seen4) and len(seen4) == 5
+    ok5 = ok5 and torch.allclose(loss4, model(x).sum().detach())
+    ok3 = ok3 and ok5
     q.put((rank, bool(ok), bool(ok2 and ok3), float(local_only.abs().sum())))
     dist.destroy_process_group()
 
