@@ -33,6 +33,10 @@ int llx_device_info(int device, char* name, int len);    /* returns CU count, fi
 
 /* ---- RMSNorm: nn.RMSNorm(D, eps=1e-5) at modelling/llama.py:158,160,182 (called :172,173,216) ----------------- */
 int llx_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int64_t rows, int64_t dim, float eps, llx_stream_t s);
+/* the same, also emitting quantize_int8_rowwise(y) (q int8 [rows,dim], row stride ldq; qscale bf16 [rows]) for the dynamic-int8-activation
+ * linears that follow the norm (subclasses/int8.py:110-113): bit-identical to llx_quantize_int8_rowwise on y, one pass */
+int llx_rmsnorm_fwd_quant(const void* x, const void* w, void* y, float* rstd, void* q, int64_t ldq, void* qscale, int64_t rows, int64_t dim,
+                          float eps, llx_stream_t s);
 int64_t llx_rmsnorm_bwd_workspace_bytes(int64_t rows, int64_t dim);
 int llx_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rstd, void* dx, void* dw /*nullable*/,
                     int dw_accumulate, void* workspace, const void* dres /*nullable: residual-branch gradient added to dx*/,

@@ -6,10 +6,14 @@
 // ---------------------------------------------------------------- forward
 // One wave per row, 4 rows per 256-thread block. Row values are kept in registers
 // (NCH chunks of 512 elements; lane owns 8 contiguous bf16 = one 16-B load per chunk).
-template <int NCH>
+// QUANT: the bf16 output row is also quantised row-wise to int8 (quantize_int8_rowwise of subclasses/int8.py:10-16 applied to y, as
+// _Int8Linear does to its input at :110-113 when dynamic_int8_act is set): absmax of the ROUNDED outputs / 127 in fp32, IEEE divide,
+// round half to even - bit-identical to llx_quantize_int8_rowwise(y), without reading y back.
+template <int NCH, bool QUANT = false>
 __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
                                                           bf16_t* __restrict__ y, float* __restrict__ rstd_out,
-                                                          int64_t rows, int dim, float eps) {
+                                                          int64_t rows, int dim, float eps, int8_t* __restrict__ q = nullptr,
+                                                          int64_t ldq = 0, bf16_t* __restrict__ qscale = nullptr) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -32,6 +36,7 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const bf16_t* __restri
   const float rstd = rsqrtf(ss / (float)dim + eps);
   if (lane == 0 && rstd_out) rstd_out[row] = rstd;
   bf16_t* yr = y + row * dim;
+  float amax = 0.f;
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
     const int col = c * 512 + lane * 8;
@@ -43,8 +48,30 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const bf16_t* __restri
         float a = bflo(v[c][e]) * rstd * bflo(wv[e]);
         float b = bfhi(v[c][e]) * rstd * bfhi(wv[e]);
         o[e] = pack_bf2(a, b);
+        if constexpr (QUANT) amax = fmaxf(amax, fmaxf(fabsf(bflo(o[e])), fabsf(bfhi(o[e]))));
       }
       *reinterpret_cast<u32x4_t*>(yr + col) = o;
+      if constexpr (QUANT) v[c] = o;  // the rounded outputs replace the inputs in registers for the quantising pass
+    }
+  }
+  if constexpr (QUANT) {
+    amax = wave_max(amax);
+    const float scale = amax / 127.0f;
+    const float div = fmaxf(scale, 1e-12f);
+    if (lane == 0) qscale[row] = f2bf(scale);
+    int8_t* qr = q + row * ldq;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int col = c * 512 + lane * 8;
+      if (col < dim) {
+        u32x2_t o = {0u, 0u};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int a = (int)rintf(bflo(v[c][e]) / div), b = (int)rintf(bfhi(v[c][e]) / div);
+          o[e >> 1] |= ((uint32_t)(a & 0xff) | ((uint32_t)(b & 0xff) << 8)) << ((e & 1) * 16);
+        }
+        *reinterpret_cast<u32x2_t*>(qr + col) = o;
+      }
     }
   }
 }
@@ -201,10 +228,26 @@ extern "C" int llx_rmsnorm_fwd(const void* x, const void* w, void* y, float* rst
   if (rows == 0) return LLX_OK;
   const dim3 grid((unsigned)cdiv64(rows, 4)), block(256);
   const int nch = (int)cdiv64(dim, 512);
-#define L(N) hipLaunchKernelGGL(rmsnorm_fwd_kernel<N>, grid, block, 0, stream, (const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y, rstd, rows, (int)dim, eps)
+#define L(N) hipLaunchKernelGGL((rmsnorm_fwd_kernel<N, false>), grid, block, 0, stream, (const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y, rstd, rows, (int)dim, eps, (int8_t*)nullptr, (int64_t)0, (bf16_t*)nullptr)
   if (nch <= 1) L(1); else if (nch <= 2) L(2); else if (nch <= 4) L(4); else if (nch <= 8) L(8); else L(16);
 #undef L
   LLX_LAUNCH_CHECK("llx_rmsnorm_fwd");
+  return LLX_OK;
+}
+
+// RMSNorm forward that also emits quantize_int8_rowwise(y): q int8 [rows, dim] (row stride ldq), qscale bf16 [rows].
+extern "C" int llx_rmsnorm_fwd_quant(const void* x, const void* w, void* y, float* rstd, void* q, int64_t ldq, void* qscale, int64_t rows,
+                                     int64_t dim, float eps, hipStream_t stream) {
+  LLX_REQUIRE(x && w && y && q && qscale, "llx_rmsnorm_fwd_quant: null pointer");
+  LLX_REQUIRE(rows >= 0 && dim > 0 && dim % 8 == 0 && dim <= 8192 && ldq % 8 == 0 && (uintptr_t)q % 8 == 0,
+              "llx_rmsnorm_fwd_quant: dim=%lld must be a multiple of 8 and <= 8192, q rows 8-byte aligned", (long long)dim);
+  if (rows == 0) return LLX_OK;
+  const dim3 grid((unsigned)cdiv64(rows, 4)), block(256);
+  const int nch = (int)cdiv64(dim, 512);
+#define L(N) hipLaunchKernelGGL((rmsnorm_fwd_kernel<N, true>), grid, block, 0, stream, (const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y, rstd, rows, (int)dim, eps, (int8_t*)q, ldq, (bf16_t*)qscale)
+  if (nch <= 1) L(1); else if (nch <= 2) L(2); else if (nch <= 4) L(4); else if (nch <= 8) L(8); else L(16);
+#undef L
+  LLX_LAUNCH_CHECK("llx_rmsnorm_fwd_quant");
   return LLX_OK;
 }
 

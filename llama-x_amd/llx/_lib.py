@@ -23,6 +23,7 @@ SIGNATURES: dict[str, tuple] = {
     "llx_last_error_string": (c_char_p, []),
     "llx_device_info": (c_int, [c_int, c_char_p, c_int]),
     "llx_rmsnorm_fwd": (c_int, [_P, _P, _P, _P, _L, _L, _F, _P]),
+    "llx_rmsnorm_fwd_quant": (c_int, [_P, _P, _P, _P, _P, _L, _P, _L, _L, _F, _P]),
     "llx_rmsnorm_bwd_workspace_bytes": (c_int64, [_L, _L]),
     "llx_rmsnorm_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _I, _P, _P, _L, _L, _P]),
     "llx_debug_attn_fwd_occupancy": (c_int, []),

@@ -43,7 +43,8 @@ def _chk_bf16(*ts):
 
 
 # ------------------------------------------------------------------------------------------------- rmsnorm
-def rmsnorm_fwd(x: Tensor, w: Tensor, eps: float) -> tuple[Tensor, Tensor]:
+def rmsnorm_fwd(x: Tensor, w: Tensor, eps: float, quant: bool = False):
+    """(y, rstd) - with quant=True also (q int8 [rows, dim], qscale bf16 [rows]) = quantize_int8_rowwise(y) from the same pass."""
     _chk_bf16(x, w)
     x2 = _rows2d(x)
     assert x2.stride(0) == x2.shape[1], "rmsnorm input rows must be dense"
@@ -51,6 +52,12 @@ def rmsnorm_fwd(x: Tensor, w: Tensor, eps: float) -> tuple[Tensor, Tensor]:
     assert w.shape == (dim,) and w.is_contiguous()
     y = torch.empty_like(x2)
     rstd = torch.empty(rows, device=x.device, dtype=torch.float32)
+    if quant:
+        q = torch.empty(rows, dim, device=x.device, dtype=torch.int8)
+        qs = torch.empty(rows, device=x.device, dtype=BF16)
+        L.check(_lib().llx_rmsnorm_fwd_quant(L.ptr(x2), L.ptr(w), L.ptr(y), L.ptr(rstd), L.ptr(q), dim, L.ptr(qs), rows, dim, eps, L.stream()),
+                "llx_rmsnorm_fwd_quant")
+        return y.view(x.shape), rstd, q, qs
     L.check(_lib().llx_rmsnorm_fwd(L.ptr(x2), L.ptr(w), L.ptr(y), L.ptr(rstd), rows, dim, eps, L.stream()), "llx_rmsnorm_fwd")
     return y.view(x.shape), rstd
 

@@ -269,12 +269,17 @@ class GroupPlan:
 
     # ---- forward
     def forward(self, x: Tensor, out: Optional[Tensor] = None, residual: Optional[Tensor] = None, swiglu_h: Optional[Tensor] = None,
-                rope: Optional[tuple[Tensor, int, int]] = None):
+                rope: Optional[tuple[Tensor, int, int]] = None, xq: Optional[tuple[Tensor, Tensor]] = None):
         """out: [M, sum N] (row-strided view allowed; allocated when None).  ``residual`` [M, sum N] is added in the GEMM
-        epilogue (x + linear(..), modelling/llama.py:172-173).  Returns (out, saved) - saved feeds backward()."""
+        epilogue (x + linear(..), modelling/llama.py:172-173).  xq = quantize_int8_rowwise(x) when the producer of x already made it
+        (the RMSNorm forward, for dynamic-int8-activation groups).  Returns (out, saved) - saved feeds backward()."""
         if out is None:
             out = torch.empty(x.shape[0], self.N, device=x.device, dtype=BF16)
-        return out, self._forward(x, out, residual, swiglu_h, rope)
+        return out, self._forward(x, out, residual, swiglu_h, rope, xq)
+
+    def wants_quantized_input(self) -> bool:
+        """The fused group runs torchao::int8_mm_dequant on row-wise quantised activations (subclasses/int8.py:110-113)."""
+        return self.fused and self.int8 and self.dynamic
 
     def rope_fusable(self) -> bool:
         """apply_rope can ride in the projection GEMM's epilogue (one fused bf16 GEMM writes the whole q|k|v row)."""
@@ -285,7 +290,7 @@ class GroupPlan:
         return self.fused and (not self.int8 or self.dynamic) and not self.dora and len(self.members) == 2 and self.Ns[0] % 128 == 0
 
     def _forward(self, x: Tensor, out: Tensor, residual: Optional[Tensor], swiglu_h: Optional[Tensor] = None,
-                 rope: Optional[tuple[Tensor, int, int]] = None):
+                 rope: Optional[tuple[Tensor, int, int]] = None, xq: Optional[tuple[Tensor, Tensor]] = None):
         if not self.fused:
             assert residual is None or len(self.members) == 1
             return [m.forward(x, out=out[:, o : o + n], residual=residual)[1] for m, o, n in zip(self.members, self.n_off, self.Ns)]
@@ -317,7 +322,7 @@ class GroupPlan:
             from subclasses.int8 import quantize_int8_rowwise
             from subclasses.int8_mm import _launch as i8_gemm
 
-            xi, xs = quantize_int8_rowwise(x)
+            xi, xs = xq if xq is not None else quantize_int8_rowwise(x)
             # one launch: int8 product dequantised in place, the adapter as bf16 K-extension, then residual / SwiGLU / RoPE epilogue
             a2, bb = (t[0], b2) if self.R > 0 else (None, None)
             if residual is not None:
@@ -554,14 +559,17 @@ class AttnBlockFn(Function):
         B, S, D = x.shape
         H, KVH, hd = meta.H, meta.KVH, meta.hd
         x2 = K._rows2d(x.contiguous())
-        if meta.fuse_norm:
+        xq = None
+        if meta.fuse_norm and meta.qkv.wants_quantized_input() and _FUSE_NORM_QUANT:
+            xn, rstd, *xq = K.rmsnorm_fwd(x2, norm_w.detach(), meta.eps, quant=True)  # the norm also emits quantize_int8_rowwise(xn)
+        elif meta.fuse_norm:
             xn, rstd = K.rmsnorm_fwd(x2, norm_w.detach(), meta.eps)
         else:
             xn, rstd = x2, None
         W = (H + 2 * KVH) * hd
         qkv = torch.empty(B * S, W, device=x.device, dtype=BF16)
         fuse_rope = meta.qkv.rope_fusable() and _FUSE_ROPE
-        _, tqkv = meta.qkv.forward(xn, qkv, rope=(rope, S, (H + KVH) * hd) if fuse_rope else None)
+        _, tqkv = meta.qkv.forward(xn, qkv, rope=(rope, S, (H + KVH) * hd) if fuse_rope else None, xq=xq)
         qkv3 = qkv.view(B, S, W)
         if not fuse_rope:
             K.rope_(qkv3, rope, H + KVH)
@@ -624,6 +632,7 @@ class AttnBlockFn(Function):
 # MLP residual branch:  [x +] w2( silu(w1 xn) * w3 xn ),  xn = [rmsnorm(x)]
 # =================================================================================================
 _FUSE_SWIGLU_FWD = os.environ.get("LLX_FUSE_SWIGLU_FWD", "1") != "0"  # A/B knob: 0 = stand-alone swiglu_fwd kernel
+_FUSE_NORM_QUANT = os.environ.get("LLX_FUSE_NORM_QUANT", "1") != "0"  # A/B knob: 0 = stand-alone activation quantiser after the RMSNorm
 _FUSE_ROPE = os.environ.get("LLX_FUSE_ROPE", "1") != "0"  # A/B knob: 0 = stand-alone rope kernel after the projection / before its dgrad
 
 
@@ -639,7 +648,10 @@ class MLPBlockFn(Function):
         K.L.require_cuda(x)
         shape = x.shape
         x2 = K._rows2d(x.contiguous())
-        if meta.fuse_norm:
+        xq = None
+        if meta.fuse_norm and meta.w13.wants_quantized_input() and _FUSE_NORM_QUANT:
+            xn, rstd, *xq = K.rmsnorm_fwd(x2, norm_w.detach(), meta.eps, quant=True)  # the norm also emits quantize_int8_rowwise(xn)
+        elif meta.fuse_norm:
             xn, rstd = K.rmsnorm_fwd(x2, norm_w.detach(), meta.eps)
         else:
             xn, rstd = x2, None
@@ -647,9 +659,9 @@ class MLPBlockFn(Function):
         gu = torch.empty(T, 2 * I, device=x.device, dtype=BF16)
         if meta.w13.swiglu_fusable() and _FUSE_SWIGLU_FWD:
             h = torch.empty(T, I, device=x.device, dtype=BF16)
-            _, t13 = meta.w13.forward(xn, gu, swiglu_h=h)  # SwiGLU in the epilogue of the gate|up GEMM
+            _, t13 = meta.w13.forward(xn, gu, swiglu_h=h, xq=xq)  # SwiGLU in the epilogue of the gate|up GEMM
         else:
-            _, t13 = meta.w13.forward(xn, gu)
+            _, t13 = meta.w13.forward(xn, gu, xq=xq)
             h = K.swiglu_fwd(gu[:, :I], gu[:, I:])
         y, t2 = meta.w2.forward(h, None, x2 if meta.fuse_residual else None)
         ctx.meta = meta

@@ -684,3 +684,21 @@ def test_dora_colscale_and_dm(K, cuda, N, Kd, ranks):
     y = K.colscale_bias(z.to(cuda), c, m.to(cuda))
     want = ((z.float() * c.cpu().float()).bfloat16().float() + m.float()).bfloat16()
     assert torch.equal(y.cpu(), want)
+
+
+@pytest.mark.parametrize("rows,dim", [(37, 512), (4096, 4096), (100, 1792)])
+def test_rmsnorm_fwd_with_fused_quantiser(K, cuda, rows, dim):
+    """K12 "fused with the preceding RMSNorm": the norm's quantising variant emits quantize_int8_rowwise(y) in the same pass -
+    bit-identical to the two-pass sequence (norm, then the stand-alone quantiser) and to the oracle's quantiser on the norm's output."""
+    from subclasses.int8 import quantize_int8_rowwise
+
+    x = _bf(O.randn("nq_x", (rows, dim), 1.7)).to(cuda)
+    x[3] = 0  # an all-zero row: y = 0, scale 0, q 0
+    w = _bf(1 + O.randn("nq_w", (dim,), 0.2)).to(cuda)
+    y0, r0 = K.rmsnorm_fwd(x, w, 1e-5)
+    y1, r1, q1, s1 = K.rmsnorm_fwd(x, w, 1e-5, quant=True)
+    assert torch.equal(y0, y1) and torch.equal(r0, r1)
+    q0, s0 = quantize_int8_rowwise(y0)
+    assert torch.equal(q1, q0) and torch.equal(s1, s0)
+    qo, so = O.quantize_int8_rowwise(y0.cpu())
+    assert torch.equal(q1.cpu(), qo) and torch.equal(s1.cpu(), so)
