@@ -144,6 +144,9 @@ int llx_skinny_tn(const void* U, const void* Y, int64_t ldy, void* out, int64_t 
 int llx_pad64(const void* in, int64_t ld, void* out, int64_t R, int64_t C, float scale, int transpose, llx_stream_t s);
 int llx_lora_group_pack(const void* const* lora_a, const void* const* lora_b, const int64_t* Ns, const int64_t* ranks, int nm, int64_t K,
                         float scale, void* a_cat, void* b2, void* bT, void* a2t, llx_stream_t s);  /* all four images, one launch (host arrays) */
+int llx_lora_groups_pack(const void* const* lora_a, const void* const* lora_b, const int64_t* Ns, const int64_t* ranks, const int* nm,
+                         const int64_t* K, const float* scale, void* const* a_cat, void* const* b2, void* const* bT, void* const* a2t, int ng,
+                         llx_stream_t s);  /* the same for up to 4 groups (one transformer layer) in one launch; host arrays, group j's members at 4*j+i */
 int llx_lora_pack(const void* in, int64_t ld, void* out, int64_t out_ld, int64_t R, int64_t C, int64_t row_off, int64_t col_off, float scale,
                   int transpose, llx_stream_t s);   /* batched LoRA operand images of a linear group (q|k|v, gate|up) */
 

@@ -296,7 +296,7 @@ extern "C" int llx_lora_pack(const void* in, int64_t ld, void* out, int64_t out_
 struct LoraMember { const bf16_t* a; const bf16_t* b; int N, n_off, r, r_off; };
 struct LoraGroup { LoraMember m[4]; int nm, K, N, R; float scale; bf16_t* a_cat; bf16_t* b2; bf16_t* bT; bf16_t* a2t; };
 
-__global__ void lora_group_pack_kernel(const LoraGroup g) {
+__device__ __forceinline__ void lora_group_pack_body(const LoraGroup& g) {
   const int64_t n_acat = (int64_t)g.R * g.K, n_b2 = (int64_t)g.N * 64, n_bT = (int64_t)g.R * g.N, n_a2t = (int64_t)g.K * 64;
   int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx < n_acat) {  // a_cat[r][k]
@@ -339,6 +339,50 @@ __global__ void lora_group_pack_kernel(const LoraGroup g) {
     }
     g.a2t[idx] = f2bf(v);
   }
+}
+
+__global__ void lora_group_pack_kernel(const LoraGroup g) { lora_group_pack_body(g); }
+
+// The operand images of up to LORA_MAX_GROUPS linear groups (the q|k|v, wo, gate|up and w2 groups of one transformer layer) in ONE
+// launch: blockIdx.y picks the group.
+#define LORA_MAX_GROUPS 4
+struct LoraGroups { LoraGroup g[LORA_MAX_GROUPS]; };
+__global__ void lora_groups_pack_kernel(const LoraGroups gs) { lora_group_pack_body(gs.g[blockIdx.y]); }
+
+static int lora_fill_group(LoraGroup& g, const void* const* lora_a, const void* const* lora_b, const int64_t* Ns, const int64_t* ranks, int nm,
+                           int64_t K, float scale, void* a_cat, void* b2, void* bT, void* a2t, int64_t* total) {
+  LLX_REQUIRE(lora_a && lora_b && Ns && ranks && nm >= 1 && nm <= 4 && a_cat && b2 && bT && a2t, "llx_lora_group_pack: bad arguments");
+  int n_off = 0, r_off = 0;
+  for (int i = 0; i < nm; ++i) {
+    g.m[i].a = (const bf16_t*)lora_a[i]; g.m[i].b = (const bf16_t*)lora_b[i];
+    g.m[i].N = (int)Ns[i]; g.m[i].n_off = n_off; g.m[i].r = (int)ranks[i]; g.m[i].r_off = r_off;
+    n_off += (int)Ns[i]; r_off += (int)ranks[i];
+  }
+  LLX_REQUIRE(r_off <= 64, "llx_lora_group_pack: total rank %d > 64", r_off);
+  g.nm = nm; g.K = (int)K; g.N = n_off; g.R = r_off; g.scale = scale;
+  g.a_cat = (bf16_t*)a_cat; g.b2 = (bf16_t*)b2; g.bT = (bf16_t*)bT; g.a2t = (bf16_t*)a2t;
+  *total = (int64_t)g.R * g.K + (int64_t)g.N * 64 + (int64_t)g.R * g.N + (int64_t)g.K * 64;
+  return LLX_OK;
+}
+
+// ng (<= 4) groups in one launch.  Group j has nm[j] members whose descriptors sit at index 4*j + i of lora_a / lora_b / Ns / ranks
+// (host arrays of length 4*ng); K[j], scale[j] and the four output images a_cat[j], b2[j], bT[j], a2t[j] per group.
+extern "C" int llx_lora_groups_pack(const void* const* lora_a, const void* const* lora_b, const int64_t* Ns, const int64_t* ranks, const int* nm,
+                                    const int64_t* K, const float* scale, void* const* a_cat, void* const* b2, void* const* bT, void* const* a2t,
+                                    int ng, hipStream_t stream) {
+  LLX_REQUIRE(nm && K && scale && a_cat && b2 && bT && a2t && ng >= 1 && ng <= LORA_MAX_GROUPS, "llx_lora_groups_pack: bad arguments (1..4 groups)");
+  LoraGroups gs;
+  int64_t most = 0;
+  for (int j = 0; j < ng; ++j) {
+    int64_t total = 0;
+    const int rc = lora_fill_group(gs.g[j], lora_a + 4 * j, lora_b + 4 * j, Ns + 4 * j, ranks + 4 * j, nm[j], K[j], scale[j], a_cat[j], b2[j], bT[j],
+                                   a2t[j], &total);
+    if (rc != LLX_OK) return rc;
+    if (total > most) most = total;
+  }
+  hipLaunchKernelGGL(lora_groups_pack_kernel, dim3((unsigned)cdiv64(most, 256), (unsigned)ng), dim3(256), 0, stream, gs);
+  LLX_LAUNCH_CHECK("llx_lora_groups_pack");
+  return LLX_OK;
 }
 
 // members: arrays of length nm (<= 4): lora_a[i] [r_i, K] and lora_b[i] [N_i, r_i], both contiguous.

@@ -55,6 +55,7 @@ SIGNATURES: dict[str, tuple] = {
     "llx_col2im3": (c_int, [_P, _P, _L, _L, _L, _L, _P]),
     "llx_conv_w_reorder": (c_int, [_P, _P, _L, _L, _I, _P]),
     "llx_lora_group_pack": (c_int, [_P, _P, _P, _P, _I, _L, _F, _P, _P, _P, _P, _P]),
+    "llx_lora_groups_pack": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "llx_lora_pack": (c_int, [_P, _L, _P, _L, _L, _L, _L, _L, _F, _I, _P]),
     "llx_pad64": (c_int, [_P, _L, _P, _L, _L, _F, _I, _P]),
     "llx_rownorm2": (c_int, [_P, _L, _P, _L, _L, _P]),

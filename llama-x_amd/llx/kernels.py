@@ -199,6 +199,43 @@ def lora_group_pack(lora_as: list, lora_bs: list, K_in: int, scale_: float):
     return a_cat, b2, bT, a2t
 
 
+def lora_groups_pack(groups: list) -> list:
+    """[(lora_as, lora_bs, K_in, scale), ...] (<= 4 linear groups, e.g. the four of one transformer layer) -> [(a_cat, b2, bT, a2t), ...]
+    as lora_group_pack builds them, from ONE launch and one buffer."""
+    import ctypes
+
+    ng = len(groups)
+    assert 1 <= ng <= 4
+    sizes, metas = [], []
+    for las, lbs, K_in, _ in groups:
+        for a, b in zip(las, lbs):
+            _chk_bf16(a, b)
+            assert a.is_contiguous() and b.is_contiguous() and a.shape[1] == K_in and b.shape[1] == a.shape[0]
+        N, R = sum(b.shape[0] for b in lbs), sum(a.shape[0] for a in las)
+        metas.append((N, R, K_in))
+        sizes.append(R * K_in + N * SK_PAD + R * N + K_in * SK_PAD)
+    dev = groups[0][0][0].device
+    buf = torch.empty(sum(sizes), device=dev, dtype=BF16)
+    out, o = [], 0
+    for (N, R, K_in) in metas:
+        a_cat = buf[o : o + R * K_in].view(R, K_in); o += R * K_in
+        b2 = buf[o : o + N * SK_PAD].view(N, SK_PAD); o += N * SK_PAD
+        bT = buf[o : o + R * N].view(R, N); o += R * N
+        a2t = buf[o : o + K_in * SK_PAD].view(K_in, SK_PAD); o += K_in * SK_PAD
+        out.append((a_cat, b2, bT, a2t))
+    PA, PB = (ctypes.c_void_p * (4 * ng))(), (ctypes.c_void_p * (4 * ng))()
+    NS, RS = (ctypes.c_int64 * (4 * ng))(), (ctypes.c_int64 * (4 * ng))()
+    NM, KS, SC = (ctypes.c_int * ng)(), (ctypes.c_int64 * ng)(), (ctypes.c_float * ng)()
+    OA, OB, OT, O2 = ((ctypes.c_void_p * ng)() for _ in range(4))
+    for j, ((las, lbs, K_in, sc), imgs) in enumerate(zip(groups, out)):
+        NM[j], KS[j], SC[j] = len(las), K_in, sc
+        for i, (a, b) in enumerate(zip(las, lbs)):
+            PA[4 * j + i], PB[4 * j + i], NS[4 * j + i], RS[4 * j + i] = a.data_ptr(), b.data_ptr(), b.shape[0], a.shape[0]
+        OA[j], OB[j], OT[j], O2[j] = (t.data_ptr() for t in imgs)
+    L.check(_lib().llx_lora_groups_pack(PA, PB, NS, RS, NM, KS, SC, OA, OB, OT, O2, ng, L.stream()), "llx_lora_groups_pack")
+    return out
+
+
 def gemm_tn(a: Tensor, b: Tensor) -> Tensor:
     """a[M,N1]^T @ b[M,N2] -> [N1,N2] (weight gradients): transposed, zero-padded copies feed the NT kernel."""
     at, bt = transpose(a, 64), transpose(b, 64)

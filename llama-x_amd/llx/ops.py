@@ -240,6 +240,7 @@ class GroupPlan:
         self.fused = (same_kind and same_scale and lora_all_or_none and dora_all_or_none and self.R <= 64
                       and all(m.bias is None for m in self.members) and all(m.K == self.K for m in self.members))
         self.int8, self.dynamic = m0.int8, m0.dynamic
+        self.packed = None  # (a_cat, b2, bT, a2t) when prepack() built the LoRA operand images of several groups in one launch
         self.scale = next((m.scale for m in self.members if m.rank > 0), 1.0)
         # true contraction length of the (block-diagonal, zero-padded) LoRA K-extension: forward sum_i N_i r_i / N, dgrad R
         self.k2_fwd = sum(n * r for n, r in zip(self.Ns, self.ranks)) / self.N
@@ -297,8 +298,8 @@ class GroupPlan:
         t = b2 = None
         if self.R > 0:
             # the four operand images (forward: a_cat, b2; backward: bT, a2t) come out of one launch and ride along in `saved`
-            a_cat, b2, bT, a2t = K.lora_group_pack([m.lora_a.detach() for m in self.members], [m.lora_b.detach() for m in self.members],
-                                                   self.K, self.scale)
+            a_cat, b2, bT, a2t = self.packed or K.lora_group_pack([m.lora_a.detach() for m in self.members],
+                                                                  [m.lora_b.detach() for m in self.members], self.K, self.scale)
             t = (K.skinny_nt(x, a_cat), bT, a2t)
         if self.dora:
             # DoRA members: the un-scaled product z is kept for d m; rescale (and residual) are their own HBM-bound passes, so RoPE /
@@ -480,6 +481,18 @@ def _save(ctx, *objs) -> None:
 def _load(ctx) -> list:
     flat = ctx.saved_tensors
     return [_dec(sp, flat) for sp in ctx._llx_spec]
+
+
+def prepack(plans: Sequence[GroupPlan]) -> None:
+    """Build the LoRA operand images of several fused groups (the four of a transformer layer) in one launch instead of one per group."""
+    todo = [p for p in plans if p.fused and p.R > 0]
+    for i in range(0, len(todo), 4):
+        chunk = todo[i : i + 4]
+        if len(chunk) < 2:
+            break
+        imgs = K.lora_groups_pack([([m.lora_a.detach() for m in p.members], [m.lora_b.detach() for m in p.members], p.K, p.scale) for p in chunk])
+        for p, im in zip(chunk, imgs):
+            p.packed = im
 
 
 def _plans_tensors(plans: Sequence[LinearPlan]) -> tuple[list[Tensor], list[int]]:

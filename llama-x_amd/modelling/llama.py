@@ -156,12 +156,15 @@ class Attention(nn.Module):
         self.wo = Linear(self.num_heads * self.head_dim, self.embed_dim, bias=False)
         self.kv_cache = None
 
-    def _run(self, x: Tensor, rope: Tensor, norm: nn.Module | None, residual: bool, mask, input_pos, block_mask) -> Tensor:
+    def plans(self):
+        return ops.GroupPlan((self.wq, self.wk, self.wv)), ops.GroupPlan((self.wo,))
+
+    def _run(self, x: Tensor, rope: Tensor, norm: nn.Module | None, residual: bool, mask, input_pos, block_mask, plans=None) -> Tensor:
         if self.kv_cache is not None or mask is not None:
             return self._run_dense(x, rope, norm, residual, mask, input_pos)
         if self.training and self.attn_dropout > 0.0:
             raise LlxError("attention dropout is not supported by the HIP attention kernel (reference default is 0.0)")
-        qkv, wo = ops.GroupPlan((self.wq, self.wk, self.wv)), ops.GroupPlan((self.wo,))
+        qkv, wo = plans or self.plans()
         meta = ops.AttnBlockMeta(qkv, wo, self.num_heads, self.num_kv_heads, self.head_dim, _as_maskspec(block_mask),
                                  norm.eps if norm is not None else 0.0, norm is not None, residual)
         tensors = qkv.tensors() + wo.tensors()
@@ -206,8 +209,11 @@ class FeedForward(nn.Module):
         self.w2 = Linear(config.intermediate_dim, config.embed_dim, bias=False)
         self.act = nn.SiLU()
 
-    def _run(self, x: Tensor, norm: nn.Module | None, residual: bool) -> Tensor:
-        w13, w2 = ops.GroupPlan((self.w1, self.w3)), ops.GroupPlan((self.w2,))
+    def plans(self):
+        return ops.GroupPlan((self.w1, self.w3)), ops.GroupPlan((self.w2,))
+
+    def _run(self, x: Tensor, norm: nn.Module | None, residual: bool, plans=None) -> Tensor:
+        w13, w2 = plans or self.plans()
         meta = ops.MLPBlockMeta(w13, w2, norm.eps if norm is not None else 0.0, norm is not None, residual)
         tensors = w13.tensors() + w2.tensors()
         return ops.MLPBlockFn.apply(x, norm.weight if norm is not None else None, meta, *tensors)
@@ -227,8 +233,12 @@ class TransformerLayer(nn.Module):
     def forward(self, x: Tensor, rope: Tensor, *, mask: Tensor | None = None, input_pos: Tensor | None = None,
                 block_mask=None) -> Tensor:
         # x + attention(attention_norm(x)) and x + feed_forward(ffn_norm(x)), each as one fused autograd node
-        x = self.attention._run(x, rope, self.attention_norm, True, mask, input_pos, block_mask)
-        return self.feed_forward._run(x, self.ffn_norm, True)
+        pa = pf = None
+        if x.is_cuda and self.attention.kv_cache is None and mask is None:
+            pa, pf = self.attention.plans(), self.feed_forward.plans()
+            ops.prepack((*pa, *pf))  # the LoRA operand images of the layer's four linear groups from one launch
+        x = self.attention._run(x, rope, self.attention_norm, True, mask, input_pos, block_mask, pa)
+        return self.feed_forward._run(x, self.ffn_norm, True, pf)
 
 
 class Llama(nn.Module):
