@@ -26,7 +26,7 @@ GF_PER_TOKEN = {4096: 34.0, 8192: 37.8}
 BF16_DENSE_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
 
 
-def build_model(cfg_name: str, seq: int, rank: int, device, config: str = "text"):
+def build_model(cfg_name: str, seq: int, rank: int, device, config: str = "text", trainable: str = "lora"):
     from modelling import Llama, LlamaAudio, LlamaConfig, apply_linear_adapter_
     from subclasses import quantize_linear_
 
@@ -63,6 +63,8 @@ def build_model(cfg_name: str, seq: int, rank: int, device, config: str = "text"
     for n, p in model.named_parameters():
         if n.startswith("layers.") and n.endswith("_norm.weight"):
             p.requires_grad_(True)  # layer norms stay trainable as in the reference scripts
+        if trainable == "reference" and n.startswith(("tok_embeddings.", "output.", "norm.")):
+            p.requires_grad_(True)  # the reference's default: only model.layers is frozen / adapted (train_metamathqa.py:177-180)
     return model.train(), cfg
 
 
@@ -158,7 +160,7 @@ def run_workload(args, config: str, device, world: int, rank: int, steps: int, w
     from llx import kernels as K
     from llx.dp import GradBuckets
 
-    model, cfg = build_model(args.model, args.seq, args.rank, device, config)
+    model, cfg = build_model(args.model, args.seq, args.rank, device, config, args.trainable)
     trainable = [p for p in model.parameters() if p.requires_grad]
     force_dp = os.environ.get("LLX_FORCE_DP") == "1"  # rehearse the N>1 code path (flat buckets + RCCL) on one GPU
     use_graph = not args.no_graph
@@ -360,6 +362,9 @@ def main():
     ap.add_argument("--config", default="text", choices=["text", "int8", "audio", "packed"],
                     help="text: BASELINE configs[1] (headline); int8: configs[3] per-GPU (INT8 frozen base, dynamic int8 activations, i8 MFMA) ; "
                          "audio: configs[2] (mel+Conv1D prefix of seq/2 audio tokens + seq/2 text tokens, prefix-LM mask, audio_embed trainable)")
+    ap.add_argument("--trainable", default="lora", choices=["lora", "reference"],
+                    help="lora: adapters + layer norms (SURVEY 8d C2, the headline); reference: also tok_embeddings / norm / output, the reference "
+                         "scripts' default trainable set (train_metamathqa.py:177-180) - weight gradients of the embedding and the LM head")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a captured hipGraph (single GPU)")
     ap.add_argument("--no-extras", action="store_true", help="skip the int8 / audio / packed workloads timed after the headline run (N=1, text only)")
@@ -382,7 +387,7 @@ def main():
     S = args.seq
     r = run_workload(args, args.config, device, world, rank, args.steps, args.warmup)
     extras = {}
-    if world == 1 and args.config == "text" and not args.no_extras and os.environ.get("LLX_FORCE_DP") != "1":
+    if world == 1 and args.config == "text" and args.trainable == "lora" and not args.no_extras and os.environ.get("LLX_FORCE_DP") != "1":
         # the other single-GPU workloads of BASELINE.json, a few replays each in the same process (reported under "configs")
         for cfg in ("int8", "audio", "packed"):
             try:
@@ -398,7 +403,8 @@ def main():
             "value": sm["value"], "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": sm["ms_per_step"], "p50_step_ms": sm["p50_step_ms"], "p10_step_ms": sm["p10_step_ms"], "p90_step_ms": sm["p90_step_ms"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": sm["workload"], "global_batch_tokens": S * world, "seq_len": S, "parallelism": f"dp{world}", "loss": sm["loss"],
+            "config": {"workload": sm["workload"] + ("; tok_embeddings / norm / output trainable too (reference default)" if args.trainable == "reference" else ""),
+                       "global_batch_tokens": S * world, "seq_len": S, "parallelism": f"dp{world}", "loss": sm["loss"],
                        "launch": sm["launch"]},
         }
         gf = GF_PER_TOKEN.get(S)

@@ -296,48 +296,73 @@ extern "C" int llx_lora_pack(const void* in, int64_t ld, void* out, int64_t out_
 struct LoraMember { const bf16_t* a; const bf16_t* b; int N, n_off, r, r_off; };
 struct LoraGroup { LoraMember m[4]; int nm, K, N, R; float scale; bf16_t* a_cat; bf16_t* b2; bf16_t* bT; bf16_t* a2t; };
 
+// One thread = 8 consecutive elements of one image row (one 16-byte store); K % 8 == 0 and N % 8 == 0 (checked by the launcher).
 __device__ __forceinline__ void lora_group_pack_body(const LoraGroup& g) {
-  const int64_t n_acat = (int64_t)g.R * g.K, n_b2 = (int64_t)g.N * 64, n_bT = (int64_t)g.R * g.N, n_a2t = (int64_t)g.K * 64;
+  const int64_t n_acat = (int64_t)g.R * g.K / 8, n_b2 = (int64_t)g.N * 8, n_bT = (int64_t)g.R * g.N / 8, n_a2t = (int64_t)g.K * 8;
   int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx < n_acat) {  // a_cat[r][k]
-    const int r = (int)(idx / g.K), k = (int)(idx % g.K);
-    bf16_t v = 0;
+  if (idx < n_acat) {  // a_cat[r][k0..k0+8): a straight copy of 16 bytes of the owning member's lora_a row
+    const int kc = g.K / 8;
+    const int r = (int)(idx / kc), k0 = (int)(idx % kc) * 8;
+    u32x4_t v = {0u, 0u, 0u, 0u};
     for (int i = 0; i < g.nm; ++i)
-      if (r >= g.m[i].r_off && r < g.m[i].r_off + g.m[i].r) v = g.m[i].a[(int64_t)(r - g.m[i].r_off) * g.K + k];
-    g.a_cat[idx] = v;
+      if (r >= g.m[i].r_off && r < g.m[i].r_off + g.m[i].r) v = *reinterpret_cast<const u32x4_t*>(g.m[i].a + (int64_t)(r - g.m[i].r_off) * g.K + k0);
+    *reinterpret_cast<u32x4_t*>(g.a_cat + (int64_t)r * g.K + k0) = v;
     return;
   }
   idx -= n_acat;
-  if (idx < n_b2) {  // b2[n][c]
-    const int n = (int)(idx >> 6), c = (int)(idx & 63);
-    float v = 0.f;
+  if (idx < n_b2) {  // b2[n][c0..c0+8) = s * lora_b_i[n - n_off][c - r_off]
+    const int n = (int)(idx >> 3), c0 = (int)(idx & 7) * 8;
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (int i = 0; i < g.nm; ++i) {
       const LoraMember& m = g.m[i];
-      if (n >= m.n_off && n < m.n_off + m.N && c >= m.r_off && c < m.r_off + m.r) v = bf2f(m.b[(int64_t)(n - m.n_off) * m.r + (c - m.r_off)]) * g.scale;
+      if (n >= m.n_off && n < m.n_off + m.N) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int c = c0 + e;
+          if (c >= m.r_off && c < m.r_off + m.r) v[e] = bf2f(m.b[(int64_t)(n - m.n_off) * m.r + (c - m.r_off)]) * g.scale;
+        }
+      }
     }
-    g.b2[idx] = f2bf(v);
+    u32x4_t o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = pack_bf2(v[2 * e], v[2 * e + 1]);
+    *reinterpret_cast<u32x4_t*>(g.b2 + (int64_t)n * 64 + c0) = o;
     return;
   }
   idx -= n_b2;
-  if (idx < n_bT) {  // bT[r][n]
-    const int r = (int)(idx / g.N), n = (int)(idx % g.N);
-    bf16_t v = 0;
+  if (idx < n_bT) {  // bT[r][n0..n0+8) = lora_b_i[n - n_off][r - r_off] (member boundaries are multiples of 8)
+    const int nc = g.N / 8;
+    const int r = (int)(idx / nc), n0 = (int)(idx % nc) * 8;
+    bf16_t v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int i = 0; i < g.nm; ++i) {
       const LoraMember& m = g.m[i];
-      if (n >= m.n_off && n < m.n_off + m.N && r >= m.r_off && r < m.r_off + m.r) v = m.b[(int64_t)(n - m.n_off) * m.r + (r - m.r_off)];
+      if (r >= m.r_off && r < m.r_off + m.r && n0 >= m.n_off && n0 < m.n_off + m.N) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = m.b[(int64_t)(n0 + e - m.n_off) * m.r + (r - m.r_off)];
+      }
     }
-    g.bT[idx] = v;
+    u32x4_t o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = (uint32_t)v[2 * e] | ((uint32_t)v[2 * e + 1] << 16);
+    *reinterpret_cast<u32x4_t*>(g.bT + (int64_t)r * g.N + n0) = o;
     return;
   }
   idx -= n_bT;
-  if (idx < n_a2t) {  // a2t[k][c]
-    const int k = (int)(idx >> 6), c = (int)(idx & 63);
-    float v = 0.f;
+  if (idx < n_a2t) {  // a2t[k][c0..c0+8) = s * lora_a_i[c - r_off][k]
+    const int k = (int)(idx >> 3), c0 = (int)(idx & 7) * 8;
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (int i = 0; i < g.nm; ++i) {
       const LoraMember& m = g.m[i];
-      if (c >= m.r_off && c < m.r_off + m.r) v = bf2f(m.a[(int64_t)(c - m.r_off) * g.K + k]) * g.scale;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int c = c0 + e;
+        if (c >= m.r_off && c < m.r_off + m.r) v[e] = bf2f(m.a[(int64_t)(c - m.r_off) * g.K + k]) * g.scale;
+      }
     }
-    g.a2t[idx] = f2bf(v);
+    u32x4_t o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = pack_bf2(v[2 * e], v[2 * e + 1]);
+    *reinterpret_cast<u32x4_t*>(g.a2t + (int64_t)k * 64 + c0) = o;
   }
 }
 
@@ -361,7 +386,11 @@ static int lora_fill_group(LoraGroup& g, const void* const* lora_a, const void* 
   LLX_REQUIRE(r_off <= 64, "llx_lora_group_pack: total rank %d > 64", r_off);
   g.nm = nm; g.K = (int)K; g.N = n_off; g.R = r_off; g.scale = scale;
   g.a_cat = (bf16_t*)a_cat; g.b2 = (bf16_t*)b2; g.bT = (bf16_t*)bT; g.a2t = (bf16_t*)a2t;
-  *total = (int64_t)g.R * g.K + (int64_t)g.N * 64 + (int64_t)g.R * g.N + (int64_t)g.K * 64;
+  LLX_REQUIRE(K % 8 == 0, "llx_lora_group_pack: K=%lld must be a multiple of 8", (long long)K);
+  for (int i = 0; i < nm; ++i) LLX_REQUIRE(Ns[i] % 8 == 0, "llx_lora_group_pack: member %d: N=%lld must be a multiple of 8", i, (long long)Ns[i]);
+  LLX_REQUIRE((((uintptr_t)a_cat | (uintptr_t)b2 | (uintptr_t)bT | (uintptr_t)a2t) & 15) == 0, "llx_lora_group_pack: the images must be 16-byte aligned");
+  for (int i = 0; i < nm; ++i) LLX_REQUIRE(((uintptr_t)lora_a[i] & 15) == 0, "llx_lora_group_pack: lora_a must be 16-byte aligned");
+  *total = ((int64_t)g.R * g.K + (int64_t)g.N * 64 + (int64_t)g.R * g.N + (int64_t)g.K * 64) / 8;  // threads: 8 elements each
   return LLX_OK;
 }
 
@@ -388,18 +417,10 @@ extern "C" int llx_lora_groups_pack(const void* const* lora_a, const void* const
 // members: arrays of length nm (<= 4): lora_a[i] [r_i, K] and lora_b[i] [N_i, r_i], both contiguous.
 extern "C" int llx_lora_group_pack(const void* const* lora_a, const void* const* lora_b, const int64_t* Ns, const int64_t* ranks, int nm, int64_t K,
                                    float scale, void* a_cat, void* b2, void* bT, void* a2t, hipStream_t stream) {
-  LLX_REQUIRE(lora_a && lora_b && Ns && ranks && nm >= 1 && nm <= 4 && a_cat && b2 && bT && a2t, "llx_lora_group_pack: bad arguments");
   LoraGroup g;
-  int n_off = 0, r_off = 0;
-  for (int i = 0; i < nm; ++i) {
-    g.m[i].a = (const bf16_t*)lora_a[i]; g.m[i].b = (const bf16_t*)lora_b[i];
-    g.m[i].N = (int)Ns[i]; g.m[i].n_off = n_off; g.m[i].r = (int)ranks[i]; g.m[i].r_off = r_off;
-    n_off += (int)Ns[i]; r_off += (int)ranks[i];
-  }
-  LLX_REQUIRE(r_off <= 64, "llx_lora_group_pack: total rank %d > 64", r_off);
-  g.nm = nm; g.K = (int)K; g.N = n_off; g.R = r_off; g.scale = scale;
-  g.a_cat = (bf16_t*)a_cat; g.b2 = (bf16_t*)b2; g.bT = (bf16_t*)bT; g.a2t = (bf16_t*)a2t;
-  const int64_t total = (int64_t)g.R * g.K + (int64_t)g.N * 64 + (int64_t)g.R * g.N + (int64_t)g.K * 64;
+  int64_t total = 0;
+  const int rc = lora_fill_group(g, lora_a, lora_b, Ns, ranks, nm, K, scale, a_cat, b2, bT, a2t, &total);
+  if (rc != LLX_OK) return rc;
   hipLaunchKernelGGL(lora_group_pack_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, stream, g);
   LLX_LAUNCH_CHECK("llx_lora_group_pack");
   return LLX_OK;
