@@ -21,6 +21,8 @@
 #define A_TILE_BYTES (256 * BK * 2)             // 32 KiB
 #define EPI_ROW_BYTES 528                       // 512 B of bf16 + 16 B pad (bank spread for the ds_write_b64)
 #define GEMM_LDS_BYTES (256 * EPI_ROW_BYTES)    // 135168 >= 2 * STAGE_BYTES
+// BNT = 128: the "half tile" (256 rows x 128 columns, waves 4 x 2, 64 x 64 per wave) used for the columns a 256-wide grid would leave
+// to a partly empty last round (see gemm_nt_bf16_impl); same LDS stage layout with a half-size B tile.
 
 enum { EPI_NONE = 0, EPI_RESIDUAL = 1, EPI_BIAS = 2, EPI_BIAS_GELU = 3, EPI_COLSCALE = 4, EPI_ROWCOLSCALE = 5, EPI_SWIGLU_BWD = 6, EPI_SWIGLU_FWD = 7, EPI_ROPE = 8 };
 
@@ -32,6 +34,7 @@ struct GemmArgs {
   int64_t lda, ldb, ldc, lde, lda2, ldb2;
   int M, N, K, K2;
   int grid_m, grid_n;
+  int col0, col_end;  // this launch computes output columns [col0, col_end) (col_end <= N); tile columns are counted from col0
   const bf16_t* sa; const bf16_t* sb;  // int8 kernel: A_scale_rowwise[M], B_scale_colwise[N] (E / lde stay free for the epilogue)
   const float* rope;       // EPI_ROPE: fp32 table [>= rope_S, 64, 2]; row m sits at position m % rope_S
   int rope_S, rope_cols;   //           columns [0, rope_cols) (whole 128-wide heads) are rotated
@@ -44,15 +47,23 @@ __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + e
 
 // I8 = true: A/B are int8 (K counted in int8 elements, 128 per tile row = the same 128-byte rows), MFMA is
 // v_mfma_i32_16x16x64_i8 with int32 accumulators, epilogue EPI_ROWCOLSCALE (torchao::int8_mm_dequant).
-template <int EPI, bool I8, int PIPE>
+template <int EPI, bool I8, int PIPE, int BNT = 256>
 __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const GemmArgs g) {
+  static_assert(BNT == 256 || BNT == 128, "tile width");
+  static_assert(BNT == 256 || (PIPE == 1 && EPI != EPI_SWIGLU_FWD), "the half tile exists for the four-phase loop only");
   constexpr int ESZ = I8 ? 1 : 2;         // bytes per element
   constexpr int TK = 128 / ESZ;           // elements per 128-byte tile row (64 bf16 | 128 int8)
+  constexpr int WNG = BNT / 64;           // wave columns (64 output columns per wave): 4 | 2
+  constexpr int WR = 256 / (8 / WNG);     // output rows per wave: 128 | 64
+  constexpr int MI = WR / 16;             // 16-row accumulator tiles per wave: 8 | 4
+  constexpr int MH = MI / 2;              // ... per phase pair
+  constexpr int BSI = BNT / 64;           // 64-row staging pieces of the B tile: 4 | 2
+  constexpr int EROW = BNT * 2 + 16;      // epilogue LDS row: the bf16 tile row + 16 B pad
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;
+  const int wm = wave / WNG, wn = wave % WNG;
 
   // ---- block -> tile: XCD-contiguous chunks (bijective remap), then 4-row groups for L2 panel reuse.
   const int nwg = g.grid_m * g.grid_n;
@@ -71,9 +82,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const GemmArgs g) {
   // units (B rows n0.. and I + n0..), so the epilogue sees g and u of one h column side by side: grid_n = I / 128.
   constexpr bool SPLITN = EPI == EPI_SWIGLU_FWD;
   const int halfN = g.N >> 1;
-  const int m0 = pid_m * BM, n0 = SPLITN ? pid_n * (BN / 2) : pid_n * BN;
+  const int m0 = pid_m * BM, n0 = SPLITN ? pid_n * (BN / 2) : g.col0 + pid_n * BNT;
   // output column (= B row) of tile-local column nl
-  auto col_of = [&](int nl) { return SPLITN ? (nl < BN / 2 ? n0 + nl : halfN + n0 + nl - BN / 2) : min(n0 + nl, g.N - 1); };
+  auto col_of = [&](int nl) { return SPLITN ? (nl < BN / 2 ? n0 + nl : halfN + n0 + nl - BN / 2) : min(n0 + nl, g.col_end - 1); };
 
   // ---- staging addresses. LDS chunk q = i*512 + tid  -> row i*64 + (tid>>3), slot tid&7;
   // source chunk = slot ^ ((row>>1)&7) = (tid&7) ^ ((tid>>4)&7)   (independent of i).
@@ -83,7 +94,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const GemmArgs g) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     arow[i] = min(m0 + i * 64 + srow, g.M - 1);  // clamp: edge rows re-read a valid row, never stored
-    brow[i] = SPLITN ? (i < 2 ? n0 + i * 64 + srow : halfN + n0 + (i - 2) * 64 + srow) : min(n0 + i * 64 + srow, g.N - 1);
+    brow[i] = SPLITN ? (i < 2 ? n0 + i * 64 + srow : halfN + n0 + (i - 2) * 64 + srow) : min(n0 + (i % BSI) * 64 + srow, g.col_end - 1);
   }
   const int nk1 = g.K / TK;
   const int nk = nk1 + g.K2 / 64;  // K-extension tiles are bf16: 64 elements per 128-byte row
@@ -120,15 +131,15 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const GemmArgs g) {
   const int frow = lane & 15;
   const int fsw = (lane >> 1) & 7;
   const int fq = lane >> 4;
-  const int a_base = (wm * 128 + frow) * 128;
+  const int a_base = (wm * WR + frow) * 128;
   const int b_base = (wn * 64 + frow) * 128;
   const int slot0 = ((0 * 4 + fq) ^ fsw) * 16;
   const int slot1 = ((1 * 4 + fq) ^ fsw) * 16;
 
   using acc_t = typename std::conditional<I8, i32x4_t, f32x4_t>::type;
-  acc_t acc[8][4];
+  acc_t acc[MI][4];
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = acc_t{0, 0, 0, 0};
 
@@ -174,22 +185,27 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const GemmArgs g) {
     // and A-hi in phase 0 of tile T-1, i.e. 5-7 phases before their first read.  LDS reuse (same 2 x 64 KiB stages):
     //   B(t) is read only in phase 0 (both 32-column halves stay in registers) -> free for B(t+2) after the phase-0 barrier
     //   A(t) is read in phases 0 and 2 -> free for A(t+2) after the phase-2 barrier.
+    // pieces (8 KiB = 64 tile rows, one global_load_lds per thread) of a half-tile: A 2, B BSI / 2
     auto stage_q = [&](int kt, int which) {  // which: 0 A-lo, 1 A-hi, 2 B-lo, 3 B-hi of K-tile kt into stage kt&1
       if (kt >= nk) return;
       const int half = which >> 1, hi = which & 1;
-      char* sT = smem + (kt & 1) * STAGE_BYTES + half * A_TILE_BYTES + hi * (A_TILE_BYTES / 2);
+      const int np = half ? BSI / 2 : 2;
+      char* sT = smem + (kt & 1) * STAGE_BYTES + half * A_TILE_BYTES + hi * np * 8192;
       if (kt < nk1) {
         const char* base = (const char*)(half ? g.B : g.A) + (int64_t)kt * 128;
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-          __builtin_amdgcn_global_load_lds((gbl_void*)(base + (half ? boff[2 * hi + j] : aoff[2 * hi + j])), (lds_void*)(sT + (j * 512 + wave * 64) * 16), 16, 0, 0);
+          if (j < np)
+            __builtin_amdgcn_global_load_lds((gbl_void*)(base + (half ? boff[np * hi + j] : aoff[2 * hi + j])), (lds_void*)(sT + (j * 512 + wave * 64) * 16), 16, 0, 0);
       } else {
         const char* base = (const char*)(half ? g.B2 : g.A2) + (int64_t)(kt - nk1) * 128;
         const int64_t l = (half ? g.ldb2 : g.lda2) * 2;  // the K-extension operands are bf16 in the int8 kernel too
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          const char* src = base + (int64_t)(half ? brow[2 * hi + j] : arow[2 * hi + j]) * l + schunk * 16;
-          __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(sT + (j * 512 + wave * 64) * 16), 16, 0, 0);
+          if (j < np) {
+            const char* src = base + (int64_t)(half ? brow[np * hi + j] : arow[2 * hi + j]) * l + schunk * 16;
+            __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(sT + (j * 512 + wave * 64) * 16), 16, 0, 0);
+          }
         }
       }
     };
@@ -213,8 +229,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const GemmArgs g) {
     auto dequant_in_place = [&]() {
       if constexpr (I8) {
 #pragma unroll
-        for (int mi = 0; mi < 8; ++mi) {
-          const float rs = bf2f(g.sa[min(m0 + wm * 128 + mi * 16 + frow, g.M - 1)]);
+        for (int mi = 0; mi < MI; ++mi) {
+          const float rs = bf2f(g.sa[min(m0 + wm * WR + mi * 16 + frow, g.M - 1)]);
 #pragma unroll
           for (int ni = 0; ni < 4; ++ni) {
             const int n = wn * 64 + ni * 16 + fq * 4;
@@ -233,13 +249,16 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const GemmArgs g) {
       auto mfma = [&](const i32x4_t& b, const i32x4_t& a, acc_t& c) { mfma_t(ext_tag, b, a, c); };
       const char* sA = smem + (kt & 1) * STAGE_BYTES;
       const char* sB = sA + A_TILE_BYTES;
-      // ---------------- phase 0: tile kt has landed once all but the 6 youngest loads (3 half-tiles of kt+1) are done
-      if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // ---------------- phase 0: tile kt has landed once all but the youngest loads (3 half-tiles of kt+1: A-lo 2 pieces, B-lo and B-hi
+      // BSI / 2 each = 6 | 4 loads per thread) are done
+      if (kt + 1 < nk) {
+        if constexpr (BSI == 4) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       stage_q(kt + 1, 1);  // A-hi of the next tile (its stage's A-hi was last read in phase 2 of tile kt-1)
-      i32x4_t bfr[2][4], af[8];  // bfr[ks][nh*2 + n2], af[ks*4 + m4]
+      i32x4_t bfr[2][4], af[2 * MH];  // bfr[ks][nh*2 + n2], af[ks*MH + m4]
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -247,54 +266,54 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const GemmArgs g) {
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int m4 = 0; m4 < 4; ++m4) af[ks * 4 + m4] = *reinterpret_cast<const i32x4_t*>(sA + a_base + m4 * 16 * 128 + (ks ? slot1 : slot0));
+        for (int m4 = 0; m4 < MH; ++m4) af[ks * MH + m4] = *reinterpret_cast<const i32x4_t*>(sA + a_base + m4 * 16 * 128 + (ks ? slot1 : slot0));
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int m4 = 0; m4 < 4; ++m4)
+        for (int m4 = 0; m4 < MH; ++m4)
 #pragma unroll
-          for (int n2 = 0; n2 < 2; ++n2) mfma(bfr[ks][n2], af[ks * 4 + m4], acc[m4][n2]);
+          for (int n2 = 0; n2 < 2; ++n2) mfma(bfr[ks][n2], af[ks * MH + m4], acc[m4][n2]);
       __builtin_amdgcn_s_setprio(0);
       asm volatile("" ::: "memory");
       __builtin_amdgcn_s_barrier();  // every wave has its B fragments: B(kt) may be overwritten
       asm volatile("" ::: "memory");
-      // ---------------- phase 1: quadrant (rows 0-63, cols 32-63)
+      // ---------------- phase 1: quadrant (first row half, cols 32-63)
       stage_q(kt + 2, 2);
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int m4 = 0; m4 < 4; ++m4)
+        for (int m4 = 0; m4 < MH; ++m4)
 #pragma unroll
-          for (int n2 = 0; n2 < 2; ++n2) mfma(bfr[ks][2 + n2], af[ks * 4 + m4], acc[m4][2 + n2]);
+          for (int n2 = 0; n2 < 2; ++n2) mfma(bfr[ks][2 + n2], af[ks * MH + m4], acc[m4][2 + n2]);
       __builtin_amdgcn_s_setprio(0);
-      // ---------------- phase 2: quadrant (rows 64-127, cols 32-63)
+      // ---------------- phase 2: quadrant (second row half, cols 32-63)
       stage_q(kt + 2, 3);
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int m4 = 0; m4 < 4; ++m4) af[ks * 4 + m4] = *reinterpret_cast<const i32x4_t*>(sA + a_base + (4 + m4) * 16 * 128 + (ks ? slot1 : slot0));
+        for (int m4 = 0; m4 < MH; ++m4) af[ks * MH + m4] = *reinterpret_cast<const i32x4_t*>(sA + a_base + (MH + m4) * 16 * 128 + (ks ? slot1 : slot0));
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int m4 = 0; m4 < 4; ++m4)
+        for (int m4 = 0; m4 < MH; ++m4)
 #pragma unroll
-          for (int n2 = 0; n2 < 2; ++n2) mfma(bfr[ks][2 + n2], af[ks * 4 + m4], acc[4 + m4][2 + n2]);
+          for (int n2 = 0; n2 < 2; ++n2) mfma(bfr[ks][2 + n2], af[ks * MH + m4], acc[MH + m4][2 + n2]);
       __builtin_amdgcn_s_setprio(0);
       asm volatile("" ::: "memory");
       __builtin_amdgcn_s_barrier();  // every wave has its second A half: A(kt) may be overwritten
       asm volatile("" ::: "memory");
-      // ---------------- phase 3: quadrant (rows 64-127, cols 0-31)
+      // ---------------- phase 3: quadrant (second row half, cols 0-31)
       stage_q(kt + 2, 0);
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int m4 = 0; m4 < 4; ++m4)
+        for (int m4 = 0; m4 < MH; ++m4)
 #pragma unroll
-          for (int n2 = 0; n2 < 2; ++n2) mfma(bfr[ks][n2], af[ks * 4 + m4], acc[4 + m4][n2]);
+          for (int n2 = 0; n2 < 2; ++n2) mfma(bfr[ks][n2], af[ks * MH + m4], acc[MH + m4][n2]);
       __builtin_amdgcn_s_setprio(0);
     };
     const int nk_main = I8 ? nk1 : nk;  // bf16: the K-extension tiles use the same MFMA and simply continue the loop
@@ -310,8 +329,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const GemmArgs g) {
 
   // ---- epilogue: acc (C^T fragments: lane owns n = fq*4..+4 for m = frow) -> bf16 -> LDS tile -> coalesced rows.
 #pragma unroll
-  for (int mi = 0; mi < 8; ++mi) {
-    const int m = wm * 128 + mi * 16 + frow;
+  for (int mi = 0; mi < MI; ++mi) {
+    const int m = wm * WR + mi * 16 + frow;
     float rs = 1.f;
     if constexpr (I8) rs = bf2f(g.sa[min(m0 + m, g.M - 1)]);  // A_scale_rowwise[m]
 #pragma unroll
@@ -335,7 +354,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const GemmArgs g) {
       u32x2_t pk;
       pk[0] = pack_bf2(c[0], c[1]);
       pk[1] = pack_bf2(c[2], c[3]);
-      *reinterpret_cast<u32x2_t*>(smem + m * EPI_ROW_BYTES + n * 2) = pk;
+      *reinterpret_cast<u32x2_t*>(smem + m * EROW + n * 2) = pk;
     }
   }
   __syncthreads();
@@ -359,12 +378,12 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const GemmArgs g) {
     return;
   }
 #pragma unroll 4
-  for (int it = 0; it < 16; ++it) {
+  for (int it = 0; it < BNT / 16; ++it) {
     const int q = it * 512 + tid;
-    const int row = q >> 5, cc = q & 31;
+    const int row = q / (BNT / 8), cc = q % (BNT / 8);
     const int gm = m0 + row, gn = n0 + cc * 8;
-    if (gm < g.M && gn < g.N) {
-      u32x4_t v = *reinterpret_cast<const u32x4_t*>(smem + row * EPI_ROW_BYTES + cc * 16);
+    if (gm < g.M && gn < g.col_end) {
+      u32x4_t v = *reinterpret_cast<const u32x4_t*>(smem + row * EROW + cc * 16);
       if constexpr (EPI == EPI_RESIDUAL) {
         // reference rounding: the linear's bf16 output is added to the bf16 residual (modelling/llama.py:172-173)
         u32x4_t r = *reinterpret_cast<const u32x4_t*>(g.E + (int64_t)gm * g.lde + gn);
@@ -418,9 +437,9 @@ static int gemm_pipe_mode() {
   return mode;
 }
 
-template <int EPI, bool I8, int PIPE>
+template <int EPI, bool I8, int PIPE, int BNT = 256>
 static int launch_gemm_p(const GemmArgs& a, hipStream_t stream) {
-  auto kern = gemm_nt_kernel<EPI, I8, PIPE>;
+  auto kern = gemm_nt_kernel<EPI, I8, PIPE, BNT>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
@@ -435,9 +454,37 @@ static int launch_gemm_p(const GemmArgs& a, hipStream_t stream) {
   return LLX_OK;
 }
 
+static int gemm_tail_mode() {  // LLX_GEMM_TAIL=0: never split off the half-tile launch (A/B knob)
+  static int mode = -1;
+  if (mode < 0) {
+    const char* e = getenv("LLX_GEMM_TAIL");
+    mode = (e && e[0] == '0') ? 0 : 1;
+  }
+  return mode;
+}
+
+// A grid of 256 x 256 tiles whose last round of 256 CUs would be at most half full (q|k|v forward: 384 tiles = 1.5 rounds; w2 data
+// gradient: 896 = 3.5) is cut in two launches: the columns that fill whole rounds with full tiles, and the remaining columns with
+// 256 x 128 half tiles (twice as many workgroups, each moving 3/4 of a full tile's operand bytes - the per-CU delivery rate, not
+// the MFMA pipe, sets a tile's time), so the last round is full and 1/4 shorter.  Results are bit-identical (same K order per output).
 template <int EPI, bool I8 = false>
 static int launch_gemm(const GemmArgs& a, hipStream_t stream) {
-  return gemm_pipe_mode() ? launch_gemm_p<EPI, I8, 1>(a, stream) : launch_gemm_p<EPI, I8, 0>(a, stream);
+  if (!gemm_pipe_mode()) return launch_gemm_p<EPI, I8, 0>(a, stream);
+  if constexpr (!I8 && EPI != EPI_SWIGLU_FWD) {
+    const int tiles = a.grid_m * a.grid_n, tail = tiles % 256;
+    if (gemm_tail_mode() && a.col0 == 0 && a.col_end == a.N && a.N % 256 == 0 && tiles > 256 && tail > 0 && tail <= 128 && tail % a.grid_m == 0) {
+      const int tail_cols = tail / a.grid_m * 256;
+      GemmArgs full = a, half = a;
+      full.col_end = a.N - tail_cols;
+      full.grid_n = a.grid_n - tail / a.grid_m;
+      half.col0 = a.N - tail_cols;
+      half.grid_n = tail_cols / 128;
+      const int rc = launch_gemm_p<EPI, I8, 1, 256>(full, stream);
+      if (rc != LLX_OK) return rc;
+      return launch_gemm_p<EPI, I8, 1, 128>(half, stream);
+    }
+  }
+  return launch_gemm_p<EPI, I8, 1>(a, stream);
 }
 
 // C[M,N] = A[M,K].B[N,K]^T (+ A2[M,K2].B2[N,K2]^T), bf16 in/out, fp32 accumulate.
@@ -470,6 +517,7 @@ static int gemm_nt_bf16_impl(const void* A, int64_t lda, const void* B, int64_t 
   a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.lde = lde; a.lda2 = lda2; a.ldb2 = ldb2;
   a.M = (int)M; a.N = (int)N; a.K = (int)K; a.K2 = (int)K2;
   a.grid_m = (int)cdiv64(M, BM); a.grid_n = (int)cdiv64(N, BN);
+  a.col0 = 0; a.col_end = (int)N;
   a.rope = rope; a.rope_S = (int)rope_S; a.rope_cols = (int)rope_cols;
   a.sa = nullptr; a.sb = nullptr;
   switch (epilogue) {
@@ -521,6 +569,7 @@ extern "C" int llx_int8_mm_dequant(const void* A, int64_t lda, const void* B, in
   a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.lde = 0; a.lda2 = 0; a.ldb2 = 0;
   a.M = (int)M; a.N = (int)N; a.K = (int)K; a.K2 = 0;
   a.grid_m = (int)cdiv64(M, BM); a.grid_n = (int)cdiv64(N, BN);
+  a.col0 = 0; a.col_end = (int)N;
   a.rope = nullptr; a.rope_S = 0; a.rope_cols = 0;
   return launch_gemm<EPI_ROWCOLSCALE, true>(a, stream);
 }
@@ -554,6 +603,7 @@ extern "C" int llx_int8_mm_dequant_ext(const void* A, int64_t lda, const void* B
   a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.lde = lde; a.lda2 = lda2; a.ldb2 = ldb2;
   a.M = (int)M; a.N = (int)N; a.K = (int)K; a.K2 = (int)K2;
   a.grid_m = (int)cdiv64(M, BM); a.grid_n = (int)cdiv64(N, BN);
+  a.col0 = 0; a.col_end = (int)N;
   a.rope = rope_table; a.rope_S = (int)rope_S; a.rope_cols = (int)rope_cols;
   switch (epilogue) {
     case EPI_RESIDUAL: return launch_gemm<EPI_RESIDUAL, true>(a, stream);

@@ -702,3 +702,47 @@ def test_rmsnorm_fwd_with_fused_quantiser(K, cuda, rows, dim):
     assert torch.equal(q1, q0) and torch.equal(s1, s0)
     qo, so = O.quantize_int8_rowwise(y0.cpu())
     assert torch.equal(q1.cpu(), qo) and torch.equal(s1.cpu(), so)
+
+
+@pytest.mark.parametrize("epi", ["none", "residual", "rope", "swiglu_bwd", "colscale"])
+def test_gemm_tail_split_half_tiles(K, cuda, epi):
+    """A grid whose last round of 256 CUs would be half empty (16 x 24 = 384 tiles here, the q|k|v forward shape; 16 x 56 = 896 for the
+    w2 data gradient) runs as two launches: full 256 x 256 tiles on the columns that fill whole rounds, 256 x 128 half tiles on the rest
+    (csrc/gemm_bf16.hip launch_gemm).  Every output column sees the same K order, so the result must equal - bit for bit - the same
+    product computed column block by column block with plain launches that do not split (<= 256 tiles each)."""
+    M, N, Kd, K2 = 4096, 6144, 512, 64
+    a = _bf(O.randn("ts_a", (M, Kd))).to(cuda)
+    b = _bf(O.randn("ts_b", (N, Kd), 0.05)).to(cuda)
+    a2 = _bf(O.randn("ts_a2", (M, K2))).to(cuda)
+    b2 = _bf(O.randn("ts_b2", (N, K2), 0.05)).to(cuda)
+    cuts = [(0, 4096), (4096, 6144)]  # 256 and 128 tiles: neither launch splits
+    if epi == "swiglu_bwd":
+        gu = _bf(O.randn("ts_gu", (M, 2 * N))).to(cuda)
+        out = torch.empty(M, 2 * N, device=cuda, dtype=torch.bfloat16)
+        K.gemm_nt(a, b, out=out, a2=a2, b2=b2, epilogue=K.EPI_SWIGLU_BWD, e=gu)
+        dh = K.gemm_nt(a, b, a2=a2, b2=b2)  # itself split; checked against the column blocks below
+        want = torch.empty_like(out)
+        K.swiglu_bwd(dh, gu[:, :N], gu[:, N:], want[:, :N], want[:, N:])
+        assert torch.equal(out, want)
+        ref = torch.cat([K.gemm_nt(a, b[lo:hi], a2=a2, b2=b2[lo:hi]) for lo, hi in cuts], 1)
+        assert torch.equal(dh, ref)
+        return
+    kw, kws = {}, [dict(), dict()]
+    if epi == "residual":
+        r = _bf(O.randn("ts_r", (M, N))).to(cuda)
+        kw = dict(epilogue=K.EPI_RESIDUAL, e=r)
+        kws = [dict(epilogue=K.EPI_RESIDUAL, e=r[:, lo:hi]) for lo, hi in cuts]
+    elif epi == "colscale":
+        cs = _bf(O.uniform("ts_cs", (N,), 0.5, 1.5)).to(cuda)
+        kw = dict(epilogue=K.EPI_COLSCALE, e=cs)
+        kws = [dict(epilogue=K.EPI_COLSCALE, e=cs[lo:hi].contiguous()) for lo, hi in cuts]
+    elif epi == "rope":
+        table = O.rope_table(O.LLAMA31_8B)[:1024].contiguous().to(cuda)
+        kw = dict(rope=(table, 1024, 5120))                      # q (4096 columns) and k (1024) rotated, v not - the split sits inside k|v
+        kws = [dict(rope=(table, 1024, 4096)), dict(rope=(table, 1024, 1024))]
+    got = K.gemm_nt(a, b, a2=a2, b2=b2, **kw)
+    ref = torch.cat([K.gemm_nt(a, b[lo:hi], a2=a2, b2=b2[lo:hi], **k) for (lo, hi), k in zip(cuts, kws)], 1)
+    assert torch.equal(got, ref)
+    full = (a.float() @ b.float().T + a2.float() @ b2.float().T)
+    if epi == "none":
+        torch.testing.assert_close(got.float(), full, atol=2 ** -7 * full.abs().max().item(), rtol=2 ** -7)
