@@ -213,10 +213,11 @@ def _cached_multi(tensors: Sequence[Tensor], tag: str, build):
     return val
 
 
-# A data-gradient GEMM whose tile count leaves the last round of 256 CUs partly empty (w2: 896 tiles = 3.5 rounds) is followed on a SIDE
-# stream by the adapter's weight-gradient kernels of the same linear (skinny_tn + reduce: independent of that GEMM): inside a replayed
-# hipGraph the two branches run concurrently and the small kernels fill the idle half of the chip (tools/probe_concurrency.py: a
-# 128-tile GEMM + 4 skinny launches take 119 us as parallel graph branches against 145 us in order).  LLX_SIDE_STREAM=0 turns it off.
+# A data-gradient GEMM whose tile count leaves the last round of 256 CUs partly empty, and whose tail the GEMM launcher cannot re-tile
+# with half tiles itself, is followed on a SIDE stream by the adapter's weight-gradient kernels of the same linear (skinny_tn + reduce:
+# independent of that GEMM): inside a replayed hipGraph the two branches run concurrently and the small kernels fill the idle part of
+# the chip (tools/probe_concurrency.py: a 128-tile GEMM + 4 skinny launches take 119 us as parallel graph branches against 145 us in
+# order; measured on the w2 data gradient before it got its half-tile tail: -0.6 ms per step).  LLX_SIDE_STREAM=0 turns it off.
 _SIDE_STREAM = os.environ.get("LLX_SIDE_STREAM", "1") != "0"
 _side_streams: dict = {}
 
@@ -257,9 +258,12 @@ class _Fork:
 
 
 def _partial_last_round(M: int, N: int) -> bool:
-    """The 256x256-tile grid of an [M, N] GEMM output ends in a round that leaves 3/8 or more of the 256 CUs idle."""
-    tail = (-(-M // 256) * -(-N // 256)) % 256
-    return 0 < tail <= 160
+    """The 256x256-tile grid of an [M, N] GEMM output ends in a round that leaves 3/8 or more of the 256 CUs idle AND the GEMM launcher
+    cannot re-tile those columns with half tiles itself (csrc/gemm_bf16.hip launch_gemm: whole tile columns, at most half a round)."""
+    gm, gn = -(-M // 256), -(-N // 256)
+    tail = (gm * gn) % 256
+    splits_itself = N % 256 == 0 and gm * gn > 256 and 0 < tail <= 128 and tail % gm == 0 and os.environ.get("LLX_GEMM_TAIL", "1") != "0"
+    return 0 < tail <= 160 and not splits_itself
 
 
 class GroupPlan:
