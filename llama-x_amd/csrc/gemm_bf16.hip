@@ -470,7 +470,7 @@ static int gemm_tail_mode() {  // LLX_GEMM_TAIL=0: never split off the half-tile
 template <int EPI, bool I8 = false>
 static int launch_gemm(const GemmArgs& a, hipStream_t stream) {
   if (!gemm_pipe_mode()) return launch_gemm_p<EPI, I8, 0>(a, stream);
-  if constexpr (!I8 && EPI != EPI_SWIGLU_FWD) {
+  if constexpr (EPI != EPI_SWIGLU_FWD) {
     const int tiles = a.grid_m * a.grid_n, tail = tiles % 256;
     if (gemm_tail_mode() && a.col0 == 0 && a.col_end == a.N && a.N % 256 == 0 && tiles > 256 && tail > 0 && tail <= 128 && tail % a.grid_m == 0) {
       const int tail_cols = tail / a.grid_m * 256;

@@ -213,59 +213,6 @@ def _cached_multi(tensors: Sequence[Tensor], tag: str, build):
     return val
 
 
-# A data-gradient GEMM whose tile count leaves the last round of 256 CUs partly empty, and whose tail the GEMM launcher cannot re-tile
-# with half tiles itself, is followed on a SIDE stream by the adapter's weight-gradient kernels of the same linear (skinny_tn + reduce:
-# independent of that GEMM): inside a replayed hipGraph the two branches run concurrently and the small kernels fill the idle part of
-# the chip (tools/probe_concurrency.py: a 128-tile GEMM + 4 skinny launches take 119 us as parallel graph branches against 145 us in
-# order; measured on the w2 data gradient before it got its half-tile tail: -0.6 ms per step).  LLX_SIDE_STREAM=0 turns it off.
-_SIDE_STREAM = os.environ.get("LLX_SIDE_STREAM", "1") != "0"
-_side_streams: dict = {}
-
-
-class _Fork:
-    """The fork point is where the object is created: the ``with`` body runs on the device's side stream after everything queued on
-    the current stream up to there; ``join()`` makes the current stream wait for the body.  Tensors allocated in the body belong to
-    the side stream's pool.  Inactive (plain in-order execution) when ``on`` is false."""
-
-    def __init__(self, device, on: bool):
-        self.on = bool(on) and _SIDE_STREAM and device.type == "cuda"
-        self.forked = False
-        if self.on:
-            self.main = torch.cuda.current_stream(device)
-            self.side = _side_streams.get(device.index)
-            if self.side is None:
-                self.side = _side_streams[device.index] = torch.cuda.Stream(device=device)
-            self.mark = torch.cuda.Event()
-            self.mark.record(self.main)
-
-    def __enter__(self):
-        if self.on:
-            self.side.wait_event(self.mark)
-            self._ctx = torch.cuda.stream(self.side)
-            self._ctx.__enter__()
-            self.forked = True
-        return self
-
-    def __exit__(self, *exc):
-        if self.on:
-            self._ctx.__exit__(*exc)
-        return False
-
-    def join(self):
-        if self.forked:
-            self.main.wait_stream(self.side)
-            self.forked = False
-
-
-def _partial_last_round(M: int, N: int) -> bool:
-    """The 256x256-tile grid of an [M, N] GEMM output ends in a round that leaves 3/8 or more of the 256 CUs idle AND the GEMM launcher
-    cannot re-tile those columns with half tiles itself (csrc/gemm_bf16.hip launch_gemm: whole tile columns, at most half a round)."""
-    gm, gn = -(-M // 256), -(-N // 256)
-    tail = (gm * gn) % 256
-    splits_itself = N % 256 == 0 and gm * gn > 256 and 0 < tail <= 128 and tail % gm == 0 and os.environ.get("LLX_GEMM_TAIL", "1") != "0"
-    return 0 < tail <= 160 and not splits_itself
-
-
 class GroupPlan:
     """Linears that read the SAME input (wq|wk|wv, w1|w3), executed as one GEMM over concatenated weight images.
 
@@ -454,11 +401,29 @@ class GroupPlan:
             t, bT, a2t = saved if saved is not None else (None, None, None)
         u = gA = gBt = None
         gB_views: Optional[list[Optional[Tensor]]] = None
-        if self.R > 0:
+        need_a, need_b = self.R > 0 and any(nd[ia] for nd in need), self.R > 0 and any(nd[ia + 1] for nd in need)
+        # (issuing the dB chain, the dA chain or both on a side stream - parallel branches of the replayed hipGraph - was measured three
+        # ways against the data-gradient GEMM and against each other: within +-0.2 ms per step of this plain order, so it stays plain)
+        # dB = s t^T.dy (and DoRA's d m): nothing here needs u
+        if self.dora and any(nd[-1] for nd in need):
+            gM = K.colsum_mul(dy_out, z, inv)
+        if need_b:
+            segs = self._tn_segs()
+            if segs is not None:  # each member's dB lands in its own contiguous block of one flat buffer: no slicing copies
+                flat = torch.empty(sum((b - a) * (d - c_) for a, b, c_, d in segs), device=dy.device, dtype=BF16)
+                K.skinny_tn(t, dy, self.R, self.scale, flat, transpose_out=True, segs=segs)
+                gB_views, off = [], 0
+                for m_, (a, b, c_, d) in zip([m for m in self.members if m.rank > 0], segs):
+                    gB_views.append(flat[off : off + (b - a) * (d - c_)].view(b - a, d - c_))
+                    off += (b - a) * (d - c_)
+            else:
+                gBt = torch.empty(self.N, self.R, device=dy.device, dtype=BF16)
+                K.skinny_tn(t, dy, self.R, self.scale, gBt, transpose_out=True)
+        if self.R > 0:  # u = dy.B, then dA = s u^T.x
             u = K.skinny_nt(dy, bT, self._kranges())  # [M,64]: column block i = dy_i @ B_i
-        # fork point: u is ready; the data-gradient GEMM is queued first, the parameter gradients behind it - on the side stream when the
-        # GEMM's grid leaves a partial last round for them to fill
-        fork = _Fork(dy.device, need_dx and self.R > 0 and _partial_last_round(dy.shape[0], self.K))
+            if need_a:
+                gA = torch.empty(self.R, self.K, device=dy.device, dtype=BF16)
+                K.skinny_tn(u, x, self.R, self.scale, gA, transpose_out=False)
         dx = None
         if need_dx:
             g = K.scale(dy, colscale=self.scale_cat()) if self.int8 else dy  # (g * scale) rounded (subclasses/int8.py:127)
@@ -466,43 +431,23 @@ class GroupPlan:
                 dx = K.gemm_nt(g, self.wt_cat(), out=swiglu[1], a2=u, b2=a2t if self.R > 0 else None, epilogue=K.EPI_SWIGLU_BWD, e=swiglu[0], k2_eff=self.R)
             else:
                 dx = K.gemm_nt(g, self.wt_cat(), out=dx_out, a2=u, b2=a2t if self.R > 0 else None, k2_eff=self.R)
-        with fork:  # parameter gradients (independent of the data-gradient GEMM)
-            if self.dora and any(nd[-1] for nd in need):
-                gM = K.colsum_mul(dy_out, z, inv)
-            if self.R > 0:
-                if any(nd[ia] for nd in need):
-                    gA = torch.empty(self.R, self.K, device=dy.device, dtype=BF16)
-                    K.skinny_tn(u, x, self.R, self.scale, gA, transpose_out=False)
-                if any(nd[ia + 1] for nd in need):
-                    segs = self._tn_segs()
-                    if segs is not None:  # each member's dB lands in its own contiguous block of one flat buffer: no slicing copies
-                        flat = torch.empty(sum((b - a) * (d - c) for a, b, c, d in segs), device=dy.device, dtype=BF16)
-                        K.skinny_tn(t, dy, self.R, self.scale, flat, transpose_out=True, segs=segs)
-                        gB_views, off = [], 0
-                        for m_, (a, b, c_, d) in zip([m for m in self.members if m.rank > 0], segs):
-                            gB_views.append(flat[off : off + (b - a) * (d - c_)].view(b - a, d - c_))
-                            off += (b - a) * (d - c_)
-                    else:
-                        gBt = torch.empty(self.N, self.R, device=dy.device, dtype=BF16)
-                        K.skinny_tn(t, dy, self.R, self.scale, gBt, transpose_out=True)
-            grads: list[Optional[Tensor]] = []
-            gb_i = 0
-            for m, nd, ro, no, n in zip(self.members, need, self.r_off, self.n_off, self.Ns):
-                j = 0
-                if not m.int8:
-                    grads.append(K.gemm_tn(dy[:, no : no + n], x) if nd[j] else None)
-                    j += 1
-                if m.rank > 0:
-                    grads.append(gA[ro : ro + m.rank] if nd[j] else None)
-                    if gB_views is not None:
-                        grads.append(gB_views[gb_i] if nd[j + 1] else None)
-                        gb_i += 1
-                    else:
-                        grads.append(gBt[no : no + n, ro : ro + m.rank].contiguous() if nd[j + 1] else None)
-                    j += 2
-                if m.dora_m is not None:
-                    grads.append(gM[no : no + n] if nd[j] else None)
-        fork.join()
+        grads: list[Optional[Tensor]] = []
+        gb_i = 0
+        for m, nd, ro, no, n in zip(self.members, need, self.r_off, self.n_off, self.Ns):
+            j = 0
+            if not m.int8:
+                grads.append(K.gemm_tn(dy[:, no : no + n], x) if nd[j] else None)
+                j += 1
+            if m.rank > 0:
+                grads.append(gA[ro : ro + m.rank] if nd[j] else None)
+                if gB_views is not None:
+                    grads.append(gB_views[gb_i] if nd[j + 1] else None)
+                    gb_i += 1
+                else:
+                    grads.append(gBt[no : no + n, ro : ro + m.rank].contiguous() if nd[j + 1] else None)
+                j += 2
+            if m.dora_m is not None:
+                grads.append(gM[no : no + n] if nd[j] else None)
         return dx, grads
 
 

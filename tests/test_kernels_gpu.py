@@ -746,3 +746,28 @@ def test_gemm_tail_split_half_tiles(K, cuda, epi):
     full = (a.float() @ b.float().T + a2.float() @ b2.float().T)
     if epi == "none":
         torch.testing.assert_close(got.float(), full, atol=2 ** -7 * full.abs().max().item(), rtol=2 ** -7)
+
+
+@pytest.mark.parametrize("K2", [0, 64])
+def test_int8_gemm_tail_split_half_tiles(K, cuda, K2):
+    """The same two-launch tiling on the i8 MFMA kernel (q|k|v projection of an int8 base: 384 tiles, RoPE epilogue, LoRA K-extension):
+    bit-identical to the product computed column block by column block with launches that do not split."""
+    from subclasses.int8_mm import _launch
+
+    M, N, Kd = 4096, 6144, 512
+    a = O.randint("its_a", (M, Kd), -127, 128).to(torch.int8).to(cuda)
+    b = O.randint("its_b", (N, Kd), -127, 128).to(torch.int8).to(cuda)
+    sa = _bf(O.uniform("its_sa", (M,), 0.001, 0.01)).to(cuda)
+    sb = _bf(O.uniform("its_sb", (N,), 0.001, 0.01)).to(cuda)
+    a2 = _bf(O.randn("its_a2", (M, K2))).to(cuda) if K2 else None
+    b2 = _bf(O.randn("its_b2", (N, K2), 0.05)).to(cuda) if K2 else None
+    table = O.rope_table(O.LLAMA31_8B)[:1024].contiguous().to(cuda)
+    cuts = [(0, 4096), (4096, 6144)]
+    for kw, kws in ((dict(), [dict(), dict()]), (dict(rope=(table, 1024, 5120)), [dict(rope=(table, 1024, 4096)), dict(rope=(table, 1024, 1024))])):
+        got = _launch(a, b, sa, sb, a2=a2, b2=b2, **kw)
+        ref = torch.cat([_launch(a, b[lo:hi], sa, sb[lo:hi].contiguous(), a2=a2, b2=None if b2 is None else b2[lo:hi], **k)
+                         for (lo, hi), k in zip(cuts, kws)], 1)
+        assert torch.equal(got, ref)
+    if K2 == 0:
+        exact = ((a.cpu().int() @ b.cpu().int().T).float() * sa.cpu().float()[:, None] * sb.cpu().float()[None, :]).bfloat16()
+        assert torch.equal(_launch(a, b, sa, sb).cpu(), exact)
