@@ -319,8 +319,10 @@ def run_workload(args, config: str, device, world: int, rank: int, steps: int, w
         for kind in ("bf16", "i8"):
             sel = [e for e in tr if e[4] == kind]
             if sel:
-                gemm_stats[kind] = {"launches": len(sel), "ms": sum(s.elapsed_time(e) for s, e, _, _, _ in sel), "flops": sum(f for _, _, f, _, _ in sel),
-                                    "alg_bytes": sum(b for _, _, _, b, _ in sel)}
+                # "launches" counts KERNEL launches (a GEMM whose last round would be half empty is two: full tiles + half tiles), as the
+                # rocprofv3 kernel table and the PMC passes do
+                gemm_stats[kind] = {"launches": sum(e[5] for e in sel), "calls": len(sel), "ms": sum(e[0].elapsed_time(e[1]) for e in sel),
+                                    "flops": sum(e[2] for e in sel), "alg_bytes": sum(e[3] for e in sel)}
     res = {"config": config, "elapsed": elapsed, "steps": steps, "warmup": warmup, "per_step": per_step, "loss": float(loss.detach()),
            "launch": launch_mode, "gemm": gemm_stats, "info": info, "S": S}
     # release the 16 GB of weights + cached images + graph pools before the next workload is built

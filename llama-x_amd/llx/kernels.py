@@ -19,12 +19,24 @@ EPI_NONE, EPI_RESIDUAL, EPI_BIAS, EPI_BIAS_GELU, EPI_COLSCALE = 0, 1, 2, 3, 4
 EPI_SWIGLU_BWD = 6  # the product is dh; e = gate|up [M, 2N]; out = dg|du [M, 2N] (dh itself is not stored)
 EPI_SWIGLU_FWD = 7  # b = [W_gate; W_up]; out = gate|up [M, N]; e = OUTPUT h [M, N/2] = silu(g) * u
 SK_PAD = 64
-# bench.py sets this to a list to collect (start_event, end_event, algorithmic ops, algorithmic bytes, "bf16" | "i8") per GEMM launch
+# bench.py sets this to a list to collect (start_event, end_event, algorithmic ops, algorithmic bytes, "bf16" | "i8", kernel launches) per GEMM call
 GEMM_TRACE = None
 
 
 def _lib():
     return L.load()
+
+
+def gemm_kernel_launches(M: int, N: int, epilogue: int) -> int:
+    """Kernel launches behind one GEMM call: 2 when the launcher re-tiles the columns of a half-empty last round with 256 x 128 tiles
+    (csrc/gemm_bf16.hip launch_gemm), else 1.  Accounting only (the GEMM trace of bench.py counts kernel launches, as rocprofv3 does)."""
+    import os
+
+    gm, gn = -(-M // 256), -(-N // 256)
+    tail = (gm * gn) % 256
+    split = (epilogue != EPI_SWIGLU_FWD and os.environ.get("LLX_GEMM_TAIL", "1") != "0" and os.environ.get("LLX_GEMM_PIPE", "1") != "0"
+             and N % 256 == 0 and gm * gn > 256 and 0 < tail <= 128 and tail % gm == 0)
+    return 2 if split else 1
 
 
 def _rows2d(x: Tensor) -> Tensor:
@@ -134,7 +146,8 @@ def gemm_nt(a: Tensor, b: Tensor, *, out: Optional[Tensor] = None, a2: Optional[
     if ev is not None:
         ev[1].record()
         kk = K + (K2 if k2_eff is None else min(float(k2_eff), K2))
-        GEMM_TRACE.append((ev[0], ev[1], 2.0 * M * N * kk, 2.0 * (M * kk + N * kk + M * N * (2 if epilogue == EPI_RESIDUAL else 1)), "bf16"))
+        GEMM_TRACE.append((ev[0], ev[1], 2.0 * M * N * kk, 2.0 * (M * kk + N * kk + M * N * (2 if epilogue == EPI_RESIDUAL else 1)), "bf16",
+                           gemm_kernel_launches(M, N, 8 if rope is not None else epilogue)))
     return out
 
 

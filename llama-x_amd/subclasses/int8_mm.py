@@ -42,7 +42,8 @@ def _launch(A: Tensor, Bt: Tensor, a_scale: Tensor, b_scale: Tensor, out: Tensor
     M, Kd = A.shape
     N = Bt.shape[0]
     # algorithmic work of the i8 kernel: the int8 product only (the bf16 LoRA extension riding in the same launch is not counted)
-    K.GEMM_TRACE.append((ev[0], ev[1], 2.0 * M * N * Kd, 1.0 * (M * Kd + N * Kd) + 2.0 * M * N * (2 if epilogue == 1 else 1), "i8"))
+    K.GEMM_TRACE.append((ev[0], ev[1], 2.0 * M * N * Kd, 1.0 * (M * Kd + N * Kd) + 2.0 * M * N * (2 if epilogue == 1 else 1), "i8",
+                         K.gemm_kernel_launches(M, N, epilogue)))
     return res
 
 
