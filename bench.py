@@ -379,12 +379,20 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+    # rehearsal of the N > 1 path on a one-GPU box: LLX_SINGLE_DEVICE=1 puts every rank on cuda:0 and LLX_DIST_BACKEND=gloo exchanges
+    # through the host (RCCL refuses two ranks on one device); the measured path is one rank per GPU over RCCL ("nccl" on ROCm)
+    if os.environ.get("LLX_SINGLE_DEVICE") == "1":
+        local = 0
+    backend = os.environ.get("LLX_DIST_BACKEND", "nccl")
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1 or os.environ.get("LLX_FORCE_DP") == "1":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", device_id=device, rank=rank, world_size=world)  # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device, rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     S = args.seq
     r = run_workload(args, args.config, device, world, rank, args.steps, args.warmup)

@@ -34,3 +34,21 @@ def test_tiny_bench_line(cuda, extra):
         assert d["roofline_i8"]["peak"] == 5000.0 and d["roofline_i8"]["unit"] == "TOP/s" and d["roofline_i8"]["traffic"] is None
     assert r["traffic"] is None  # no PMC file exists for a tiny plumbing workload
     assert "workload" in d["config"] and "model" not in d["config"]
+
+
+@pytest.mark.gpu
+def test_two_rank_bench_rehearsal_on_one_gpu(cuda):
+    """The default `--gpus N` path (StagedStep: per-stage hipGraphs, bucket exchange between them) with TWO ranks, launched exactly as the
+    driver launches it.  A one-GPU box cannot give each rank its own device and RCCL refuses two ranks on one device, so both ranks sit
+    on cuda:0 (LLX_SINGLE_DEVICE=1) and exchange through gloo (LLX_DIST_BACKEND=gloo): plumbing, not performance."""
+    env = dict(os.environ, LLX_SINGLE_DEVICE="1", LLX_DIST_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29641",
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--model", "tiny", "--seq", "512", "--steps", "3", "--warmup", "2"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, "rank 0 prints ONE JSON line"
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and d["config"]["global_batch_tokens"] == 1024
+    assert "RCCL all-reduce of stage k under the backward of stage k-1" in d["config"]["launch"] and "cpu_baseline" not in d and "configs" not in d
+    assert abs(d["value"] - 1024 / (d["ms_per_step"] * 1e-3)) < 0.02 * d["value"]
