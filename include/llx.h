@@ -61,6 +61,13 @@ int llx_gemm_nt_bf16_rope(const void* A, int64_t lda, const void* B, int64_t ldb
                           const void* A2, int64_t lda2, const void* B2, int64_t ldb2, int64_t K2, const float* rope_table, int64_t rope_S,
                           int64_t rope_cols, llx_stream_t s);
 
+/* ---- the weight gradient of a dense linear, dW[out,in] = dy[T,out]^T . x[T,in] (autograd of F.linear for the weights the scripts leave
+ *      trainable: tok_embeddings / norm / output by default, train_metamathqa.py:177-180; the Conv1d weights of modelling/audio.py:26-31 as
+ *      an implicit GEMM): C[N1,N2] = A[M,N1]^T . B[M,N2], operands read as they lie (token-major rows, row-strided views allowed), no
+ *      transposed copies.  N1, N2 multiples of 8; any M. ------------------------------------------------------------------------------- */
+int llx_gemm_tn_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M, int64_t N1, int64_t N2,
+                     llx_stream_t s);
+
 /* ---- torchao::int8_mm_dequant(A, B, A_scale, B_scale) - subclasses/int8_mm.py:121-149 (Triton kernel :50-118).
  *      A int8 [M,K]; B passed as its K-contiguous rows [N,K] (= the reference's int_data.T view, strides (1,K));
  *      scales bf16; C bf16 = (int32 acc) * a_scale[m] * b_scale[n], one rounding.  K multiple of 128. ----------- */

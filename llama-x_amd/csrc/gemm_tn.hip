@@ -1,0 +1,201 @@
+// bf16 MFMA GEMM, "TN" form:  C[N1,N2] = A[M,N1]^T . B[M,N2]   (fp32 accumulate, bf16 out).
+//
+// The weight gradient of a dense linear: dW[out,in] = dy[T,out]^T . x[T,in] - reference: autograd of F.linear at
+// modelling/llama.py:118-120,140,152,216 for every weight the scripts leave trainable (tok_embeddings / norm / output by default,
+// train_metamathqa.py:177-180) and of the Conv1d weights of the audio front end (modelling/audio.py:26-31) as an implicit GEMM.
+// Both operands are read as they lie in memory (row = token): no transposed copies.
+//
+// Tile 256 x 256 x 64 (8 waves, 2 x 4, v_mfma_f32_16x16x32_bf16), two 64-KiB LDS stages filled by global_load_lds.  A K-tile is 64
+// token rows of 256 columns = a k-major image [64][256] (512-B rows); the MFMA fragments (8 consecutive k for one column) come out
+// of it through ds_read_b64_tr_b16 pairs.  A 32-lane read group touches 8 image rows x 32 B; with 512-B rows they would share one
+// 32-B bank window, so the 16-B chunks of a row are XOR-swizzled by key(row) = (row & 3) | ((row >> 3) & 1) << 2 on the SOURCE
+// address (the LDS image stays lane-linear for the DMA) and on the read address.
+#include "common.h"
+
+#define TBM 256
+#define TBN 256
+#define TBK 64
+#define T_TILE_BYTES (TBK * 256 * 2)      // 32 KiB: one operand, 64 k-rows x 512 B
+#define T_STAGE_BYTES (2 * T_TILE_BYTES)  // A + B
+#define T_EROW 528
+#define TN_LDS_BYTES (256 * T_EROW)       // epilogue staging (135168 B) >= 2 stages (131072 B)
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
+typedef __attribute__((address_space(3))) s16x4_t lds_s16x4t;
+typedef __attribute__((ext_vector_type(8))) short s16x8t;
+
+struct GemmTnArgs {
+  const bf16_t* A; const bf16_t* B; bf16_t* C;
+  int64_t lda, ldb, ldc;
+  int M, N1, N2;  // contraction length, output rows, output columns
+  int grid_m, grid_n;
+};
+
+__device__ __forceinline__ int tn_key(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
+
+// 16x16x32 operand for output index c0 + (lane & 15), k = 8 * (lane >> 4) + j of the 32-row k-step at `tile` (k-major, 512-B rows,
+// chunk swizzle as above).
+__device__ __forceinline__ bf16x8_t tn_frag(const char* tile, int c0, int lane) {
+  const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+  const int col = c0 + 4 * p;                    // first of the 4 columns this lane's 8 bytes cover
+  const int chunk = col >> 3, half = (col & 4) << 1;  // 16-B chunk, byte offset of the 8-B half
+  const int r0 = 8 * g + q, r1 = r0 + 4;
+  const char* p0 = tile + r0 * 512 + ((chunk ^ (tn_key(r0) << 1)) << 4) + half;
+  const char* p1 = tile + r1 * 512 + ((chunk ^ (tn_key(r1) << 1)) << 4) + half;
+  const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4t*)p0);
+  const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4t*)p1);
+  const s16x8t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8_t, v);
+}
+
+__global__ __launch_bounds__(512, 2) void gemm_tn_kernel(const GemmTnArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+
+  // block -> tile: XCD-contiguous chunks, then 4-row groups (as the NT kernel)
+  const int nwg = g.grid_m * g.grid_n;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
+    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+  }
+  const int GROUP_M = 4;
+  const int width = GROUP_M * g.grid_n;
+  const int group = bid / width;
+  const int gsz = min(g.grid_m - group * GROUP_M, GROUP_M);
+  const int pid_m = group * GROUP_M + ((bid % width) % gsz);
+  const int pid_n = (bid % width) / gsz;
+  const int m0 = pid_m * TBM, n0 = pid_n * TBN;  // output row (A column) / output column (B column) origin
+
+  // staging: LDS chunk q = i*512 + tid -> image row (q >> 5), chunk (q & 31); source chunk = chunk ^ (key(row) << 1).
+  // The image row of a thread's i-th piece is i*16 + (tid >> 5); key() only uses row bits 0,1,3 -> it depends on i through bit 3
+  // of i*16 (none) ... computed per piece below (cheap, outside the loop).
+  uint32_t aoff[4], boff[4];
+  int srow[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = i * 16 + (tid >> 5);
+    const int chunk = (tid & 31) ^ (tn_key(row) << 1);
+    srow[i] = row;
+    const int ca = min(m0 + chunk * 8, g.N1 - 8);  // clamp: edge columns re-read valid ones, never stored
+    const int cb = min(n0 + chunk * 8, g.N2 - 8);
+    aoff[i] = (uint32_t)ca * 2;
+    boff[i] = (uint32_t)cb * 2;
+  }
+  const int nk = (g.M + TBK - 1) / TBK;
+  auto stage = [&](int buf, int kt) {
+    char* sA = smem + buf * T_STAGE_BYTES;
+    char* sB = sA + T_TILE_BYTES;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int64_t m = min(kt * TBK + srow[i], g.M - 1);  // rows past the end are re-reads of the last row; their products are zeroed
+      __builtin_amdgcn_global_load_lds((gbl_void*)((const char*)g.A + m * g.lda * 2 + aoff[i]), (lds_void*)(sA + (i * 512 + wave * 64) * 16), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_void*)((const char*)g.B + m * g.ldb * 2 + boff[i]), (lds_void*)(sB + (i * 512 + wave * 64) * 16), 16, 0, 0);
+    }
+  };
+
+  f32x4_t acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  stage(0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) {
+      stage(cur ^ 1, kt + 1);  // its buffer was last read in iteration kt-1, behind that iteration's closing barrier
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // all but the 8 loads just issued: tile kt has landed (this wave's pieces)
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();  // ... and every other wave's pieces
+    asm volatile("" ::: "memory");
+    const char* sA = smem + cur * T_STAGE_BYTES;
+    const char* sB = sA + T_TILE_BYTES;
+    const bool ragged = kt * TBK + TBK > g.M;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8_t bfr[4], af[8];
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) bfr[ni] = tn_frag(sB + ks * 32 * 512, wn * 64 + ni * 16, lane);
+#pragma unroll
+      for (int mi = 0; mi < 8; ++mi) af[mi] = tn_frag(sA + ks * 32 * 512, wm * 128 + mi * 16, lane);
+      if (ragged) {  // last K-tile of a contraction length that is not a multiple of 64: zero the A fragments of rows past M
+        const int k0 = kt * TBK + ks * 32 + 8 * (lane >> 4);
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) {
+          s16x8t v = __builtin_bit_cast(s16x8t, af[mi]);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = (k0 + j < g.M) ? v[j] : (short)0;
+          af[mi] = __builtin_bit_cast(bf16x8_t, v);
+        }
+      }
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ni], af[mi], acc[mi][ni], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // every wave is done reading stage `cur`: the next iteration may refill it
+    asm volatile("" ::: "memory");
+  }
+
+  // epilogue: C^T fragments (lane owns columns n = fq*4..+4 of row m = frow) -> bf16 -> LDS tile -> 512-B row stores
+  const int frow = lane & 15, fq = lane >> 4;
+#pragma unroll
+  for (int mi = 0; mi < 8; ++mi) {
+    const int m = wm * 128 + mi * 16 + frow;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      const int n = wn * 64 + ni * 16 + fq * 4;
+      u32x2_t pk;
+      pk[0] = pack_bf2(acc[mi][ni][0], acc[mi][ni][1]);
+      pk[1] = pack_bf2(acc[mi][ni][2], acc[mi][ni][3]);
+      *reinterpret_cast<u32x2_t*>(smem + m * T_EROW + n * 2) = pk;
+    }
+  }
+  __syncthreads();
+#pragma unroll 4
+  for (int it = 0; it < 16; ++it) {
+    const int q = it * 512 + tid;
+    const int row = q >> 5, cc = q & 31;
+    const int gm = m0 + row, gn = n0 + cc * 8;
+    if (gm < g.N1 && gn < g.N2)
+      *reinterpret_cast<u32x4_t*>(g.C + (int64_t)gm * g.ldc + gn) = *reinterpret_cast<const u32x4_t*>(smem + row * T_EROW + cc * 16);
+  }
+}
+
+// C[N1,N2] = A[M,N1]^T . B[M,N2], bf16 in / out, fp32 accumulate.  lda / ldb / ldc: row strides in elements (multiples of 8; A and B
+// may be row-strided views, e.g. the im2col view of a convolution input).  N1, N2 multiples of 8 and >= 8; any M >= 1.
+extern "C" int llx_gemm_tn_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M, int64_t N1, int64_t N2,
+                                hipStream_t stream) {
+  LLX_REQUIRE(A && B && C, "llx_gemm_tn_bf16: null pointer");
+  LLX_REQUIRE(M > 0 && N1 >= 8 && N2 >= 8 && N1 % 8 == 0 && N2 % 8 == 0, "llx_gemm_tn_bf16: need M > 0 and N1, N2 multiples of 8 (M=%lld N1=%lld N2=%lld)",
+              (long long)M, (long long)N1, (long long)N2);
+  LLX_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && ldc % 8 == 0, "llx_gemm_tn_bf16: row strides must be multiples of 8 elements");
+  LLX_REQUIRE(((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) % 16 == 0, "llx_gemm_tn_bf16: pointers must be 16-byte aligned");
+  LLX_REQUIRE(M < (1 << 30) && N1 < (1 << 30) && N2 < (1 << 30), "llx_gemm_tn_bf16: dimension too large");
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS_BYTES);
+    if (e != hipSuccess) {
+      llx_set_error("llx_gemm_tn_bf16: cannot raise dynamic LDS limit: %s", hipGetErrorString(e));
+      return LLX_ERR_LAUNCH;
+    }
+    attr_set = true;
+  }
+  GemmTnArgs a;
+  a.A = (const bf16_t*)A; a.B = (const bf16_t*)B; a.C = (bf16_t*)C;
+  a.lda = lda; a.ldb = ldb; a.ldc = ldc;
+  a.M = (int)M; a.N1 = (int)N1; a.N2 = (int)N2;
+  a.grid_m = (int)cdiv64(N1, TBM); a.grid_n = (int)cdiv64(N2, TBN);
+  hipLaunchKernelGGL(gemm_tn_kernel, dim3(a.grid_m * a.grid_n), dim3(512), TN_LDS_BYTES, stream, a);
+  LLX_LAUNCH_CHECK("llx_gemm_tn_bf16");
+  return LLX_OK;
+}

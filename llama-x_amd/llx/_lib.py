@@ -69,6 +69,7 @@ SIGNATURES: dict[str, tuple] = {
     "llx_skinny_tn_workspace_bytes": (c_int64, [_L, _L, _L]),
     "llx_skinny_tn": (c_int, [_P, _P, _L, _P, _L, _L, _L, _L, _F, _I, _I, _P, _P, _I, _P]),
     "llx_gemm_nt_bf16": (c_int, [_P, _L, _P, _L, _P, _L, _L, _L, _L, _P, _L, _P, _L, _L, _I, _P, _L, _P]),
+    "llx_gemm_tn_bf16": (c_int, [_P, _L, _P, _L, _P, _L, _L, _L, _L, _P]),
     "llx_gemm_nt_bf16_rope": (c_int, [_P, _L, _P, _L, _P, _L, _L, _L, _L, _P, _L, _P, _L, _L, _P, _L, _L, _P]),
 }
 

@@ -250,9 +250,27 @@ def lora_groups_pack(groups: list) -> list:
 
 
 def gemm_tn(a: Tensor, b: Tensor) -> Tensor:
-    """a[M,N1]^T @ b[M,N2] -> [N1,N2] (weight gradients): transposed, zero-padded copies feed the NT kernel."""
-    at, bt = transpose(a, 64), transpose(b, 64)
-    return gemm_nt(at, bt)
+    """a[M,N1]^T @ b[M,N2] -> [N1,N2] (weight gradients of dense linears / convolutions): the TN MFMA kernel reads both operands as they
+    lie (token-major rows, row-strided views allowed).  Shapes it does not take (a dimension below 8 or not a multiple of 8, unaligned
+    views) go through transposed, zero-padded copies and the NT kernel."""
+    _chk_bf16(a, b)
+    assert a.dim() == 2 and b.dim() == 2 and a.shape[0] == b.shape[0] and a.stride(1) == 1 and b.stride(1) == 1
+    M, N1 = a.shape
+    N2 = b.shape[1]
+    ok = (N1 % 8 == 0 and N2 % 8 == 0 and N1 >= 8 and N2 >= 8 and a.stride(0) % 8 == 0 and b.stride(0) % 8 == 0
+          and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0)
+    if not ok:
+        return gemm_nt(transpose(a, 64), transpose(b, 64))
+    out = torch.empty(N1, N2, device=a.device, dtype=BF16)
+    ev = None
+    if GEMM_TRACE is not None:
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
+    L.check(_lib().llx_gemm_tn_bf16(L.ptr(a), a.stride(0), L.ptr(b), b.stride(0), L.ptr(out), out.stride(0), M, N1, N2, L.stream()), "llx_gemm_tn_bf16")
+    if ev is not None:
+        ev[1].record()
+        GEMM_TRACE.append((ev[0], ev[1], 2.0 * M * N1 * N2, 2.0 * (M * N1 + M * N2 + N1 * N2), "bf16_tn", 1))
+    return out
 
 
 def i8_to_bf16(x: Tensor) -> Tensor:

@@ -771,3 +771,31 @@ def test_int8_gemm_tail_split_half_tiles(K, cuda, K2):
     if K2 == 0:
         exact = ((a.cpu().int() @ b.cpu().int().T).float() * sa.cpu().float()[:, None] * sb.cpu().float()[None, :]).bfloat16()
         assert torch.equal(_launch(a, b, sa, sb).cpu(), exact)
+
+
+@pytest.mark.parametrize("M,N1,N2", [(256, 256, 256), (4096, 1024, 4096), (2000, 4096, 384), (1000, 520, 264), (37, 8, 16), (4096, 128256 // 8, 512)])
+def test_gemm_tn(K, cuda, M, N1, N2):
+    """llx_gemm_tn_bf16: C = A^T.B with both operands read token-major (the dense weight gradient) against fp32 math; contraction
+    lengths that are not multiples of 64 (zeroed tail), ragged output tiles, and twice the same launch bit-identical."""
+    a = _bf(O.randn("tn_a", (M, N1))).to(cuda)
+    b = _bf(O.randn("tn_b", (M, N2))).to(cuda)
+    c = K.gemm_tn(a, b)
+    ref = a.float().T @ b.float()
+    tol = 2 ** -7 * ref.abs().max().item()
+    torch.testing.assert_close(c.float(), ref, atol=tol, rtol=2 ** -7)
+    assert torch.equal(c, K.gemm_tn(a, b))
+
+
+def test_gemm_tn_strided_views_and_fallback(K, cuda):
+    """Row-strided operands (the im2col VIEW of a k=3, stride-2 convolution input; a column slice of a fused gradient buffer) go
+    straight into the TN kernel; shapes it does not take (a dimension that is not a multiple of 8) fall back to the transposed copies."""
+    D, L2 = 512, 333
+    h1 = _bf(O.randn("tn_h1", (2 * L2 + 1, D))).to(cuda)
+    A2 = torch.as_strided(h1, (L2, 3 * D), (2 * D, 1))      # overlapping rows: row l = h1[2l : 2l+3] flattened
+    dz = _bf(O.randn("tn_dz", (L2, 1024))).to(cuda)
+    got = K.gemm_tn(dz[:, 256:768], A2)                      # column slice (row stride 1024) x strided view
+    ref = dz[:, 256:768].float().T @ A2.float()
+    torch.testing.assert_close(got.float(), ref, atol=2 ** -7 * ref.abs().max().item(), rtol=2 ** -7)
+    small = K.gemm_tn(dz[:, :4], A2)                          # N1 = 4: fallback path
+    ref = dz[:, :4].float().T @ A2.float()
+    torch.testing.assert_close(small.float(), ref, atol=2 ** -7 * ref.abs().max().item(), rtol=2 ** -7)
