@@ -27,7 +27,7 @@ extern "C" {
 typedef void* llx_stream_t; /* hipStream_t */
 
 /* ---- library ------------------------------------------------------------------------------------------------ */
-int llx_version(void);                                   /* 100 = 0.1.0 */
+int llx_version(void);                                   /* 101 = 0.1.1 */
 const char* llx_last_error_string(void);                 /* thread-local, valid until the next failing call */
 int llx_device_info(int device, char* name, int len);    /* returns CU count, fills gcn arch name */
 

@@ -23,7 +23,7 @@ def test_header_and_library_agree():
         assert name in L.SIGNATURES, f"{name} has no ctypes signature in llx/_lib.py"
     for name in L.SIGNATURES:
         assert name in declared, f"{name} bound in llx/_lib.py but missing from include/llx.h"
-    assert lib.llx_version() == 100
+    assert lib.llx_version() == 101
     assert isinstance(lib.llx_last_error_string(), (bytes, type(None)))
 
 
