@@ -49,7 +49,7 @@ class GradBuckets:
             target = (total + n_buckets - 1) // max(1, n_buckets)
             cur, cur_n = [], 0
             for p in params:
-                if cur and (cur_n + p.numel() > target or p.dtype != cur[0].dtype) and len(self.buckets) < n_buckets - 1:
+                if cur and (p.dtype != cur[0].dtype or (cur_n + p.numel() > target and len(self.buckets) < n_buckets - 1)):
                     self.buckets.append(self._make(cur))
                     cur, cur_n = [], 0
                 cur.append(p)
