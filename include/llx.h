@@ -143,6 +143,10 @@ int llx_ce_fwd_bwd(const void* logits, int64_t ld, void* dlogits, int64_t dld, c
  *      G = s * U^T.Y with fp32 split partials (deterministic). --------------------------------------------------- */
 int llx_skinny_nt(const void* X, int64_t ldx, const void* W, int64_t ldw, void* out, int64_t M, int64_t K, int64_t R,
                   const int32_t* kranges /* host, nullable: {lo,hi} x 4 per 16 rows of a block-diagonal W */, llx_stream_t s);
+/* nn.RMSNorm (modelling/llama.py:158-160) and the adapter's x @ lora_a^T on its output (modelling/lora.py:43) from ONE read of x:
+ * y = rmsnorm(x) [M,D], rstd fp32 [M], t = y . W^T [M,64 padded] (W = the group's stacked lora_a [R,D]).  D % 512 == 0, D <= 4096. */
+int llx_rmsnorm_skinny_nt(const void* x, const void* g, const void* W, int64_t ldw, void* y, float* rstd, void* t, int64_t M, int64_t D,
+                          int64_t R, float eps, llx_stream_t s);
 int64_t llx_skinny_tn_workspace_bytes(int64_t M, int64_t N, int64_t R);
 int llx_skinny_tn(const void* U, const void* Y, int64_t ldy, void* out, int64_t out_ld, int64_t M, int64_t N, int64_t R, float scale,
                   int transpose_out, int accumulate, void* workspace,

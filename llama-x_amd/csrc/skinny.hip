@@ -312,3 +312,118 @@ extern "C" int llx_skinny_tn(const void* U, const void* Y, int64_t ldy, void* ou
   LLX_LAUNCH_CHECK("llx_skinny_tn(reduce)");
   return LLX_OK;
 }
+
+// ------------------------------------------------------------------------------------------ RMSNorm + NT in one pass
+// y = rmsnorm(x) (nn.RMSNorm, modelling/llama.py:158-160: fp32 math, one rounding) AND t = y . W^T [M, 64 padded] (the adapter's
+// x @ lora_a^T of modelling/lora.py:43 on the NORMED activations) from ONE read of x: the rows are already on chip when the norm is
+// applied, in exactly the fragment layout the skinny MFMA product wants.  Block = 16 rows, 8 waves; wave w holds the 16 x (D/8)
+// slice k in [w*D/8, (w+1)*D/8) of the rows in registers (pair-contiguous k map of skinny_nt_kernel: whole 128-B lines per row).
+// Same math as llx_rmsnorm_fwd followed by llx_skinny_nt(y, W) with different fp32 summation orders (the squares of a row are summed
+// per fragment lane, the product over contiguous k slices per wave): rstd agrees to ~1e-7, y and t to one bf16 ulp in rare elements;
+// deterministic run to run, and the backward uses the rstd saved here.
+#define RSN_MAXPAIRS 8  // D / 8 waves / 64 = pairs per wave: D <= 4096
+
+template <int NB>
+__global__ __launch_bounds__(SNT_WAVES * 64) void rmsnorm_skinny_nt_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ G,
+                                                                           const bf16_t* __restrict__ W, int64_t ldw, bf16_t* __restrict__ Y,
+                                                                           float* __restrict__ rstd_out, bf16_t* __restrict__ T, int M, int D,
+                                                                           int R, float eps) {
+  __shared__ float part[SNT_WAVES][16][SK_PAD];
+  __shared__ float ssq[SNT_WAVES][16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int m0 = blockIdx.x * 16;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int row = min(m0 + fr, M - 1);
+  const int npw = D / (SNT_WAVES * 64);  // pairs (64 k each) per wave, <= RSN_MAXPAIRS
+  const bf16_t* xrow = X + (int64_t)row * D + wave * npw * 64 + 16 * fq;
+  bf16x8_t a[RSN_MAXPAIRS][2];
+  float ss = 0.f;
+#pragma unroll
+  for (int p = 0; p < RSN_MAXPAIRS; ++p) {
+    if (p < npw) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        a[p][h] = *reinterpret_cast<const bf16x8_t*>(xrow + p * 64 + 8 * h);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float v = (float)a[p][h][j];
+          ss += v * v;
+        }
+      }
+    }
+  }
+  // row sums: across the 4 k-groups of a row (lanes fr + 16*fq), then across the 8 waves
+  ss += __shfl_xor(ss, 16, 64);
+  ss += __shfl_xor(ss, 32, 64);
+  if (fq == 0) ssq[wave][fr] = ss;
+  __syncthreads();
+  float tot = 0.f;
+#pragma unroll
+  for (int w = 0; w < SNT_WAVES; ++w) tot += ssq[w][fr];
+  const float rstd = rsqrtf(tot / (float)D + eps);
+  if (wave == 0 && fq == 0 && m0 + fr < M && rstd_out) rstd_out[m0 + fr] = rstd;
+  // normalise in registers (single rounding to bf16), store y, and feed the rounded values to the MFMAs
+  const bf16_t* grow = G + wave * npw * 64 + 16 * fq;
+  bf16_t* yrow = Y + (int64_t)row * D + wave * npw * 64 + 16 * fq;
+  const bf16_t* wrow[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) wrow[nb] = W + (int64_t)min(nb * 16 + fr, R - 1) * ldw + wave * npw * 64 + 16 * fq;
+  f32x4_t acc[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) acc[nb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int p = 0; p < RSN_MAXPAIRS; ++p) {
+    if (p < npw) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const bf16x8_t gv = *reinterpret_cast<const bf16x8_t*>(grow + p * 64 + 8 * h);
+        bf16x8_t y;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) y[j] = (__bf16)((float)a[p][h][j] * rstd * (float)gv[j]);
+        if (m0 + fr < M) *reinterpret_cast<bf16x8_t*>(yrow + p * 64 + 8 * h) = y;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          const bf16x8_t b = *reinterpret_cast<const bf16x8_t*>(wrow[nb] + p * 64 + 8 * h);
+          acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(y, b, acc[nb], 0, 0, 0);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) part[wave][fq * 4 + e][nb * 16 + fr] = acc[nb][e];
+  __syncthreads();
+  const int orow = threadIdx.x >> 5, c0 = (threadIdx.x & 31) * 2;
+  if (m0 + orow < M) {
+    float v[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int c = c0 + e;
+      float s = 0.f;
+      if (c < NB * 16 && c < R) {
+#pragma unroll
+        for (int w = 0; w < SNT_WAVES; ++w) s += part[w][orow][c];
+      }
+      v[e] = s;
+    }
+    *reinterpret_cast<uint32_t*>(T + (int64_t)(m0 + orow) * SK_PAD + c0) = pack_bf2(v[0], v[1]);
+  }
+}
+
+// x, y: [M, D] bf16 dense rows; g: norm weight [D]; W: [R, D] (row stride ldw); rstd fp32 [M]; t: [M, 64] bf16 (columns >= R zero).
+// D a multiple of 512 and <= 4096 (8 waves x 64-wide k pairs); R <= 64.
+extern "C" int llx_rmsnorm_skinny_nt(const void* x, const void* g, const void* W, int64_t ldw, void* y, float* rstd, void* t, int64_t M,
+                                     int64_t D, int64_t R, float eps, hipStream_t stream) {
+  LLX_REQUIRE(x && g && W && y && t, "llx_rmsnorm_skinny_nt: null pointer");
+  LLX_REQUIRE(M > 0 && D > 0 && D % (SNT_WAVES * 64) == 0 && D <= SNT_WAVES * 64 * RSN_MAXPAIRS && R > 0 && R <= 64,
+              "llx_rmsnorm_skinny_nt: need D a multiple of 512 and <= 4096, 0 < R <= 64 (D=%lld R=%lld)", (long long)D, (long long)R);
+  LLX_REQUIRE(ldw % 8 == 0 && ((uintptr_t)x | (uintptr_t)g | (uintptr_t)W | (uintptr_t)y) % 16 == 0 && (uintptr_t)t % 8 == 0, "llx_rmsnorm_skinny_nt: alignment");
+  const dim3 grid((unsigned)cdiv64(M, 16)), block(SNT_WAVES * 64);
+  const int nb = (int)cdiv64(R, 16);
+#define L(N) hipLaunchKernelGGL((rmsnorm_skinny_nt_kernel<N>), grid, block, 0, stream, (const bf16_t*)x, (const bf16_t*)g, (const bf16_t*)W, ldw, (bf16_t*)y, rstd, (bf16_t*)t, (int)M, (int)D, (int)R, eps)
+  if (nb == 1) L(1); else if (nb == 2) L(2); else L(4);
+#undef L
+  LLX_LAUNCH_CHECK("llx_rmsnorm_skinny_nt");
+  return LLX_OK;
+}

@@ -74,6 +74,25 @@ def rmsnorm_fwd(x: Tensor, w: Tensor, eps: float, quant: bool = False):
     return y.view(x.shape), rstd
 
 
+def rmsnorm_skinny_ok(dim: int) -> bool:
+    return dim % 512 == 0 and dim <= 4096
+
+
+def rmsnorm_skinny_nt(x: Tensor, w: Tensor, eps: float, a_cat: Tensor) -> tuple[Tensor, Tensor, Tensor]:
+    """(y, rstd, t): y = rmsnorm(x), t = y @ a_cat^T [rows, 64] (zero beyond column R) from one read of x (csrc/skinny.hip)."""
+    _chk_bf16(x, w, a_cat)
+    x2 = _rows2d(x)
+    rows, dim = x2.shape
+    assert x2.stride(0) == dim and w.shape == (dim,) and w.is_contiguous() and rmsnorm_skinny_ok(dim)
+    assert a_cat.dim() == 2 and a_cat.shape[1] == dim and a_cat.stride(1) == 1 and a_cat.shape[0] <= SK_PAD
+    y = torch.empty_like(x2)
+    rstd = torch.empty(rows, device=x.device, dtype=torch.float32)
+    t = torch.empty(rows, SK_PAD, device=x.device, dtype=BF16)
+    L.check(_lib().llx_rmsnorm_skinny_nt(L.ptr(x2), L.ptr(w), L.ptr(a_cat), a_cat.stride(0), L.ptr(y), L.ptr(rstd), L.ptr(t), rows, dim,
+                                         a_cat.shape[0], eps, L.stream()), "llx_rmsnorm_skinny_nt")
+    return y.view(x.shape), rstd, t
+
+
 def rmsnorm_bwd(dy: Tensor, x: Tensor, w: Tensor, rstd: Tensor, need_dw: bool, dres: Optional[Tensor] = None) -> tuple[Tensor, Optional[Tensor]]:
     """dx (+ dres, the gradient coming around the residual connection, joined in the same pass), dw."""
     _chk_bf16(dy, x, w, dres)

@@ -270,13 +270,17 @@ class GroupPlan:
 
     # ---- forward
     def forward(self, x: Tensor, out: Optional[Tensor] = None, residual: Optional[Tensor] = None, swiglu_h: Optional[Tensor] = None,
-                rope: Optional[tuple[Tensor, int, int]] = None, xq: Optional[tuple[Tensor, Tensor]] = None):
+                rope: Optional[tuple[Tensor, int, int]] = None, xq: Optional[tuple[Tensor, Tensor]] = None, t_pre: Optional[Tensor] = None):
         """out: [M, sum N] (row-strided view allowed; allocated when None).  ``residual`` [M, sum N] is added in the GEMM
-        epilogue (x + linear(..), modelling/llama.py:172-173).  xq = quantize_int8_rowwise(x) when the producer of x already made it
-        (the RMSNorm forward, for dynamic-int8-activation groups).  Returns (out, saved) - saved feeds backward()."""
+        epilogue (x + linear(..), modelling/llama.py:172-173).  xq = quantize_int8_rowwise(x) / t_pre = x @ A_cat^T when the producer of
+        x already made them (the RMSNorm forward).  Returns (out, saved) - saved feeds backward()."""
         if out is None:
             out = torch.empty(x.shape[0], self.N, device=x.device, dtype=BF16)
-        return out, self._forward(x, out, residual, swiglu_h, rope, xq)
+        return out, self._forward(x, out, residual, swiglu_h, rope, xq, t_pre)
+
+    def norm_can_make_t(self, dim: int) -> bool:
+        """The preceding RMSNorm can emit t = xn @ A_cat^T itself: the operand images exist already (prepack) and the width fits."""
+        return self.fused and self.R > 0 and self.packed is not None and K.rmsnorm_skinny_ok(dim) and _FUSE_NORM_SKINNY
 
     def wants_quantized_input(self) -> bool:
         """The fused group runs torchao::int8_mm_dequant on row-wise quantised activations (subclasses/int8.py:110-113)."""
@@ -291,7 +295,7 @@ class GroupPlan:
         return self.fused and (not self.int8 or self.dynamic) and not self.dora and len(self.members) == 2 and self.Ns[0] % 128 == 0
 
     def _forward(self, x: Tensor, out: Tensor, residual: Optional[Tensor], swiglu_h: Optional[Tensor] = None,
-                 rope: Optional[tuple[Tensor, int, int]] = None, xq: Optional[tuple[Tensor, Tensor]] = None):
+                 rope: Optional[tuple[Tensor, int, int]] = None, xq: Optional[tuple[Tensor, Tensor]] = None, t_pre: Optional[Tensor] = None):
         if not self.fused:
             assert residual is None or len(self.members) == 1
             return [m.forward(x, out=out[:, o : o + n], residual=residual)[1] for m, o, n in zip(self.members, self.n_off, self.Ns)]
@@ -300,7 +304,7 @@ class GroupPlan:
             # the four operand images (forward: a_cat, b2; backward: bT, a2t) come out of one launch and ride along in `saved`
             a_cat, b2, bT, a2t = self.packed or K.lora_group_pack([m.lora_a.detach() for m in self.members],
                                                                   [m.lora_b.detach() for m in self.members], self.K, self.scale)
-            t = (K.skinny_nt(x, a_cat), bT, a2t)
+            t = (t_pre if t_pre is not None else K.skinny_nt(x, a_cat), bT, a2t)
         if self.dora:
             # DoRA members: the un-scaled product z is kept for d m; rescale (and residual) are their own HBM-bound passes, so RoPE /
             # SwiGLU run stand-alone after this group (rope_fusable / swiglu_fusable are False)
@@ -574,9 +578,11 @@ class AttnBlockFn(Function):
         B, S, D = x.shape
         H, KVH, hd = meta.H, meta.KVH, meta.hd
         x2 = K._rows2d(x.contiguous())
-        xq = None
+        xq = t_pre = None
         if meta.fuse_norm and meta.qkv.wants_quantized_input() and _FUSE_NORM_QUANT:
             xn, rstd, *xq = K.rmsnorm_fwd(x2, norm_w.detach(), meta.eps, quant=True)  # the norm also emits quantize_int8_rowwise(xn)
+        elif meta.fuse_norm and meta.qkv.norm_can_make_t(D):
+            xn, rstd, t_pre = K.rmsnorm_skinny_nt(x2, norm_w.detach(), meta.eps, meta.qkv.packed[0])  # ... or the adapters' xn @ A_cat^T
         elif meta.fuse_norm:
             xn, rstd = K.rmsnorm_fwd(x2, norm_w.detach(), meta.eps)
         else:
@@ -584,7 +590,7 @@ class AttnBlockFn(Function):
         W = (H + 2 * KVH) * hd
         qkv = torch.empty(B * S, W, device=x.device, dtype=BF16)
         fuse_rope = meta.qkv.rope_fusable() and _FUSE_ROPE
-        _, tqkv = meta.qkv.forward(xn, qkv, rope=(rope, S, (H + KVH) * hd) if fuse_rope else None, xq=xq)
+        _, tqkv = meta.qkv.forward(xn, qkv, rope=(rope, S, (H + KVH) * hd) if fuse_rope else None, xq=xq, t_pre=t_pre)
         qkv3 = qkv.view(B, S, W)
         if not fuse_rope:
             K.rope_(qkv3, rope, H + KVH)
@@ -647,6 +653,7 @@ class AttnBlockFn(Function):
 # MLP residual branch:  [x +] w2( silu(w1 xn) * w3 xn ),  xn = [rmsnorm(x)]
 # =================================================================================================
 _FUSE_SWIGLU_FWD = os.environ.get("LLX_FUSE_SWIGLU_FWD", "1") != "0"  # A/B knob: 0 = stand-alone swiglu_fwd kernel
+_FUSE_NORM_SKINNY = os.environ.get("LLX_FUSE_NORM_SKINNY", "1") != "0"  # A/B knob: 0 = RMSNorm, then the stand-alone skinny product
 _FUSE_NORM_QUANT = os.environ.get("LLX_FUSE_NORM_QUANT", "1") != "0"  # A/B knob: 0 = stand-alone activation quantiser after the RMSNorm
 _FUSE_ROPE = os.environ.get("LLX_FUSE_ROPE", "1") != "0"  # A/B knob: 0 = stand-alone rope kernel after the projection / before its dgrad
 
@@ -663,9 +670,11 @@ class MLPBlockFn(Function):
         K.L.require_cuda(x)
         shape = x.shape
         x2 = K._rows2d(x.contiguous())
-        xq = None
+        xq = t_pre = None
         if meta.fuse_norm and meta.w13.wants_quantized_input() and _FUSE_NORM_QUANT:
             xn, rstd, *xq = K.rmsnorm_fwd(x2, norm_w.detach(), meta.eps, quant=True)  # the norm also emits quantize_int8_rowwise(xn)
+        elif meta.fuse_norm and meta.w13.norm_can_make_t(x2.shape[1]):
+            xn, rstd, t_pre = K.rmsnorm_skinny_nt(x2, norm_w.detach(), meta.eps, meta.w13.packed[0])  # ... or the adapters' xn @ A_cat^T
         elif meta.fuse_norm:
             xn, rstd = K.rmsnorm_fwd(x2, norm_w.detach(), meta.eps)
         else:
@@ -674,9 +683,9 @@ class MLPBlockFn(Function):
         gu = torch.empty(T, 2 * I, device=x.device, dtype=BF16)
         if meta.w13.swiglu_fusable() and _FUSE_SWIGLU_FWD:
             h = torch.empty(T, I, device=x.device, dtype=BF16)
-            _, t13 = meta.w13.forward(xn, gu, swiglu_h=h, xq=xq)  # SwiGLU in the epilogue of the gate|up GEMM
+            _, t13 = meta.w13.forward(xn, gu, swiglu_h=h, xq=xq, t_pre=t_pre)  # SwiGLU in the epilogue of the gate|up GEMM
         else:
-            _, t13 = meta.w13.forward(xn, gu, xq=xq)
+            _, t13 = meta.w13.forward(xn, gu, xq=xq, t_pre=t_pre)
             h = K.swiglu_fwd(gu[:, :I], gu[:, I:])
         y, t2 = meta.w2.forward(h, None, x2 if meta.fuse_residual else None)
         ctx.meta = meta

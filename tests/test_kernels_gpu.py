@@ -799,3 +799,27 @@ def test_gemm_tn_strided_views_and_fallback(K, cuda):
     small = K.gemm_tn(dz[:, :4], A2)                          # N1 = 4: fallback path
     ref = dz[:, :4].float().T @ A2.float()
     torch.testing.assert_close(small.float(), ref, atol=2 ** -7 * ref.abs().max().item(), rtol=2 ** -7)
+
+
+@pytest.mark.parametrize("rows,dim,R", [(37, 512, 8), (4096, 4096, 48), (300, 1024, 16), (256, 4096, 32)])
+def test_rmsnorm_with_fused_adapter_projection(K, cuda, rows, dim, R):
+    """RMSNorm forward that also emits t = y @ A_cat^T (csrc/skinny.hip rmsnorm_skinny_nt_kernel).  Same math as the stand-alone norm
+    and skinny product with different fp32 summation orders (the row's squares are summed per MFMA-fragment lane, the product per
+    contiguous k slice): rstd to 1e-6, y within one bf16 ulp of the stand-alone norm AND of the oracle, t within one ulp of
+    skinny_nt(y, A_cat); columns >= R zero; deterministic."""
+    x = _bf(O.randn("rs_x", (rows, dim), 1.3)).to(cuda)
+    w = _bf(1 + O.randn("rs_w", (dim,), 0.2)).to(cuda)
+    a = _bf(O.randn("rs_a", (R, dim), 0.05)).to(cuda)
+    y0, r0 = K.rmsnorm_fwd(x, w, 1e-5)
+    y1, r1, t1 = K.rmsnorm_skinny_nt(x, w, 1e-5, a)
+    torch.testing.assert_close(r1, r0, rtol=2e-6, atol=0)
+    torch.testing.assert_close(y1.float(), y0.float(), rtol=2 ** -7, atol=0)
+    want = O.rmsnorm(x.cpu().float(), w.cpu().float())
+    torch.testing.assert_close(y1.cpu().float(), want, rtol=2 ** -7, atol=1e-6)
+    assert (y1 != y0).float().mean().item() < 0.01, "only rare last-bit differences against the stand-alone norm"
+    t0 = K.skinny_nt(y1, a)
+    assert t1.shape == (rows, 64) and float(t1[:, R:].abs().max()) == 0.0
+    ref = y1.float() @ a.float().T
+    torch.testing.assert_close(t1[:, :R].float(), ref, atol=2 ** -8 * ref.abs().max().item(), rtol=2 ** -7)
+    torch.testing.assert_close(t1.float(), t0.float(), atol=2 ** -8 * ref.abs().max().item(), rtol=2 ** -7)
+    assert torch.equal(t1, K.rmsnorm_skinny_nt(x, w, 1e-5, a)[2])
