@@ -126,48 +126,48 @@ WORKLOAD_TEXT = {
     "packed": "Llama-3.1-8B text-only LoRA r={rank} bf16, seq={S} packed from {n_docs} synthetic documents (log-normal lengths), document mask "
               "(BASELINE.json configs[1], packed variant of SURVEY 8d C2)",
     "audio": "Llama-3.1-8B + mel/Conv1D audio prefix ({St} audio tokens from {samples} samples) + {St} text tokens, prefix-LM mask, LoRA r={rank} + "
-             "trainable audio_embed (BASELINE.json configs[2])",
+             "trainable audio_embed (BASELINE.json configs[2]; at seq 8192 the per-GPU shape of configs[4])",
 }
 PEAK = {"bf16": (2500.0, "TFLOP/s", "gemm_nt_kernel<EPI, false, 1> (bf16 MFMA GEMM, v_mfma_f32_16x16x32_bf16)"),
         "i8": (5000.0, "TOP/s", "gemm_nt_kernel<EPI, true, 1> (i8 MFMA GEMM = torchao::int8_mm_dequant, v_mfma_i32_16x16x64_i8)")}
 
 
-def _traffic(args, config: str, kind: str):
+def _traffic(args, config: str, kind: str, S: int):
     """HBM bytes per launch from the PMC passes committed under profiles/ FOR THIS workload (model, config, sequence length) and kernel
     (bench.py cannot run rocprofv3 on itself); None when no such file exists - a number measured on another workload is not a
     measurement of this one."""
     if args.model != "llama31_8b":
         return None
     try:
-        with open(os.path.join(ROOT, "profiles", f"r02_{config}_s{args.seq}_{kind}_gemm_hbm_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", f"r02_{config}_s{S}_{kind}_gemm_hbm_traffic.json")) as f:
             return round(json.load(f)["hbm_bytes_per_launch"])
     except (OSError, KeyError, ValueError):
         return None
 
 
-def _roofline(args, config: str, kind: str, st: dict) -> dict:
+def _roofline(args, config: str, kind: str, st: dict, S: int) -> dict:
     peak, unit, kernel = PEAK[kind]
     ach = st["flops"] / (st["ms"] * 1e-3) / 1e12
-    return {"bound": "mfma", "achieved": round(ach, 1), "peak": peak, "unit": unit, "frac": round(ach / peak, 4), "traffic": _traffic(args, config, kind),
+    return {"bound": "mfma", "achieved": round(ach, 1), "peak": peak, "unit": unit, "frac": round(ach / peak, 4), "traffic": _traffic(args, config, kind, S),
             "algorithmic_bytes_per_launch": round(st["alg_bytes"] / max(1, st["launches"])), "kernel": kernel,
             "launches_per_step": st["launches"], "avg_launch_us": round(st["ms"] * 1e3 / max(1, st["launches"]), 2),
             "gemm_ms_per_step": round(st["ms"], 2)}
 
 
-def run_workload(args, config: str, device, world: int, rank: int, steps: int, warmup: int) -> dict:
+def run_workload(args, config: str, device, world: int, rank: int, steps: int, warmup: int, seq: int | None = None) -> dict:
     """Build the model of one BASELINE configuration, capture its step, time `steps` steps after `warmup`, then trace one eager step with
     HIP events around every GEMM launch (bf16 and i8 kernels separately).  Returns the raw numbers; main() formats them."""
     from llx import kernels as K
     from llx.dp import GradBuckets
 
-    model, cfg = build_model(args.model, args.seq, args.rank, device, config, args.trainable)
+    S = seq or args.seq
+    model, cfg = build_model(args.model, S, args.rank, device, config, args.trainable)
     trainable = [p for p in model.parameters() if p.requires_grad]
     force_dp = os.environ.get("LLX_FORCE_DP") == "1"  # rehearse the N>1 code path (flat buckets + RCCL) on one GPU
     use_graph = not args.no_graph
     dp = world > 1 or force_dp
     optim = torch.optim.AdamW(trainable, lr=1e-4, weight_decay=0.0, fused=True, capturable=use_graph)
 
-    S = args.seq
     gen = torch.Generator(device=device)
     gen.manual_seed(rank)  # rank-distinct data streams
     audio_cfg = config == "audio"
@@ -347,9 +347,9 @@ def _summary(args, r: dict, world: int) -> dict:
     g = {k: v for k, v in r["gemm"].items() if v["ms"] > 0}
     if g:
         dominant = max(g, key=lambda k: g[k]["ms"])  # the kernel the step spends most of its time in
-        d["roofline"] = _roofline(args, r["config"], dominant, g[dominant])
+        d["roofline"] = _roofline(args, r["config"], dominant, g[dominant], r["S"])
         if "i8" in g:
-            d["roofline_i8"] = _roofline(args, r["config"], "i8", g["i8"])  # int8_mm_dequant against the 5.0 POP/s i8 MFMA peak
+            d["roofline_i8"] = _roofline(args, r["config"], "i8", g["i8"], r["S"])  # int8_mm_dequant against the 5.0 POP/s i8 MFMA peak
     return d
 
 
@@ -399,9 +399,10 @@ def main():
     extras = {}
     if world == 1 and args.config == "text" and args.trainable == "lora" and not args.no_extras and os.environ.get("LLX_FORCE_DP") != "1":
         # the other single-GPU workloads of BASELINE.json, a few replays each in the same process (reported under "configs")
-        for cfg in ("int8", "audio", "packed"):
+        # (+ the per-GPU shape of configs[4]: 4096 audio + 4096 text tokens, S = 8192, when the headline runs at its default length)
+        for cfg, sq in (("int8", None), ("audio", None), ("packed", None)) + ((("audio_s8192", 8192),) if args.seq == 4096 and args.model == "llama31_8b" else ()):
             try:
-                extras[cfg] = _summary(args, run_workload(args, cfg, device, world, rank, args.extra_steps, 2), world)
+                extras[cfg] = _summary(args, run_workload(args, cfg.split("_")[0], device, world, rank, args.extra_steps, 2, seq=sq), world)
             except Exception as exc:  # noqa: BLE001 - an extra workload must not cost the headline line
                 extras[cfg] = {"error": f"{type(exc).__name__}: {exc}"}
                 print(f"[bench] extra workload {cfg} failed: {exc}", file=sys.stderr, flush=True)
