@@ -152,6 +152,13 @@ int llx_skinny_tn(const void* U, const void* Y, int64_t ldy, void* out, int64_t 
                   int transpose_out, int accumulate, void* workspace,
                   const int32_t* segs /* host, nullable: {n_lo, n_hi, r_lo, r_hi} per member of a fused group; member blocks are
                                          then written one after another as contiguous [n, r] matrices */, int seg_count, llx_stream_t s);
+/* the two stages of llx_skinny_tn separately: the fp32 split partials of one product, and the second stage of up to 4 products (the
+ * adapter gradients of one transformer block) in ONE launch; host arrays of length n, entry i = the arguments of product i */
+int llx_skinny_tn_partial(const void* U, const void* Y, int64_t ldy, int64_t M, int64_t N, int64_t R, void* workspace, const int32_t* segs,
+                          int seg_count, llx_stream_t s);
+int llx_skinny_tn_reduce_many(int n, const void* const* workspaces, void* const* outs, const int64_t* out_ld, const int64_t* M, const int64_t* N,
+                              const int64_t* R, const float* scale, const int* transpose_out, const int* accumulate,
+                              const int32_t* const* segs, const int* seg_count, llx_stream_t s);
 int llx_pad64(const void* in, int64_t ld, void* out, int64_t R, int64_t C, float scale, int transpose, llx_stream_t s);
 int llx_lora_group_pack(const void* const* lora_a, const void* const* lora_b, const int64_t* Ns, const int64_t* ranks, int nm, int64_t K,
                         float scale, void* a_cat, void* b2, void* bT, void* a2t, llx_stream_t s);  /* all four images, one launch (host arrays) */

@@ -213,40 +213,7 @@ __global__ __launch_bounds__(256) void skinny_tn_kernel(const bf16_t* __restrict
     }
 }
 
-// out = bf16(scale * sum_split partial[split][r][n] (+ out));  transpose_out: out is [N, R] (ld = out_ld) else [R, N].
-__global__ void skinny_tn_reduce_kernel(const float* __restrict__ partial, bf16_t* __restrict__ out, int64_t out_ld, int nsplit, int RP, int R,
-                                        int N, float scale, int transpose_out, int accumulate) {
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (int64_t)R * N) return;
-  const int r = (int)(idx / N), n = (int)(idx % N);
-  float s = 0.f;
-  for (int p = 0; p < nsplit; ++p) s += partial[((int64_t)p * RP + r) * N + n];
-  s *= scale;
-  bf16_t* dst = transpose_out ? out + (int64_t)n * out_ld + r : out + (int64_t)r * out_ld + n;
-  if (accumulate) s += bf2f(*dst);
-  *dst = f2bf(s);
-}
-
-// segment form: thread -> (member, n, r); out + off[member] is that member's contiguous [n_hi - n_lo, r_hi - r_lo] gradient
-__global__ void skinny_tn_reduce_segs_kernel(const float* __restrict__ partial, bf16_t* __restrict__ out, int nsplit, int RP, int N, float scale,
-                                             int accumulate, TnSegs sg) {
-  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  int m = 0;
-  for (; m < sg.count; ++m) {
-    const int64_t cnt = (int64_t)(sg.n_hi[m] - sg.n_lo[m]) * (sg.r_hi[m] - sg.r_lo[m]);
-    if (idx < cnt) break;
-    idx -= cnt;
-  }
-  if (m >= sg.count) return;
-  const int rw = sg.r_hi[m] - sg.r_lo[m];
-  const int n = sg.n_lo[m] + (int)(idx / rw), r = sg.r_lo[m] + (int)(idx % rw);
-  float s = 0.f;
-  for (int p = 0; p < nsplit; ++p) s += partial[((int64_t)p * RP + r) * N + n];
-  s *= scale;
-  bf16_t* dst = out + sg.off[m] + idx;
-  if (accumulate) s += bf2f(*dst);
-  *dst = f2bf(s);
-}
+// (second stage: skinny_tn_reduce_many_kernel below - out = bf16(scale * sum_split partial[split][r][n] (+ out)), plain [R,N] / [N,R] or member segments)
 
 static int tn_splits(int64_t M, int64_t N) {
   const int64_t ntiles = cdiv64(N, TN_NT);
@@ -262,20 +229,8 @@ extern "C" int64_t llx_skinny_tn_workspace_bytes(int64_t M, int64_t N, int64_t R
   return (int64_t)tn_splits(M, N) * cdiv64(R, 16) * 16 * N * 4;
 }
 
-// U: [M, 64] bf16 (row stride 64; columns >= R ignored), Y: [M, N] (row stride ldy).  workspace as above.
-// segs (host pointer, nullable): up to 4 members {n_lo, n_hi, r_lo, r_hi} (n bounds multiples of 256 or N), seg_count of them:
-// only those blocks of the [N, R] product are computed, and member i's block is written transposed-out as a contiguous
-// [n_hi - n_lo, r_hi - r_lo] matrix at out + sum_{j<i} size_j (out_ld and transpose_out are ignored).
-extern "C" int llx_skinny_tn(const void* U, const void* Y, int64_t ldy, void* out, int64_t out_ld, int64_t M, int64_t N, int64_t R,
-                             float scale, int transpose_out, int accumulate, void* workspace, const int32_t* segs, int seg_count,
-                             hipStream_t stream) {
-  LLX_REQUIRE(U && Y && out && workspace, "llx_skinny_tn: null pointer");
-  LLX_REQUIRE(M > 0 && N > 0 && N % 8 == 0 && R > 0 && R <= 64 && ldy % 8 == 0, "llx_skinny_tn: need N%%8==0, ldy%%8==0, 0<R<=64");
-  LLX_REQUIRE(((uintptr_t)U | (uintptr_t)Y) % 16 == 0, "llx_skinny_tn: unaligned pointer");
-  const int nsplit = tn_splits(M, N);
-  int rows_per_split = (int)cdiv64(cdiv64(M, nsplit), TN_MS) * TN_MS;
-  const int nb = (int)cdiv64(R, 16);
-  TnSegs sg;
+// segment table of a fused group's dB^T (host side): validates and fills sg; returns the number of output elements.
+static int tn_fill_segs(TnSegs& sg, const int32_t* segs, int seg_count, int64_t N, int64_t R, int64_t* total_out) {
   sg.count = 0;
   for (int rb = 0; rb < 4; ++rb) { sg.rb_lo[rb] = 0; sg.rb_hi[rb] = (int)N; }
   int64_t total = 0;
@@ -296,21 +251,106 @@ extern "C" int llx_skinny_tn(const void* U, const void* Y, int64_t ldy, void* ou
     }
     sg.count = seg_count;
   }
+  *total_out = total;
+  return LLX_OK;
+}
+
+// first stage only: fp32 split partials of U^T.Y into the workspace (llx_skinny_tn_workspace_bytes); llx_skinny_tn_reduce_many finishes.
+extern "C" int llx_skinny_tn_partial(const void* U, const void* Y, int64_t ldy, int64_t M, int64_t N, int64_t R, void* workspace,
+                                     const int32_t* segs, int seg_count, hipStream_t stream) {
+  LLX_REQUIRE(U && Y && workspace, "llx_skinny_tn: null pointer");
+  LLX_REQUIRE(M > 0 && N > 0 && N % 8 == 0 && R > 0 && R <= 64 && ldy % 8 == 0, "llx_skinny_tn: need N%%8==0, ldy%%8==0, 0<R<=64");
+  LLX_REQUIRE(((uintptr_t)U | (uintptr_t)Y) % 16 == 0, "llx_skinny_tn: unaligned pointer");
+  const int nsplit = tn_splits(M, N);
+  int rows_per_split = (int)cdiv64(cdiv64(M, nsplit), TN_MS) * TN_MS;
+  const int nb = (int)cdiv64(R, 16);
+  TnSegs sg;
+  int64_t total = 0;
+  const int rc = tn_fill_segs(sg, segs, seg_count, N, R, &total);
+  if (rc != LLX_OK) return rc;
   const dim3 grid((unsigned)cdiv64(N, TN_NT), (unsigned)nsplit), block(256);
 #define L(NBV) hipLaunchKernelGGL(skinny_tn_kernel<NBV>, grid, block, 0, stream, (const bf16_t*)U, (const bf16_t*)Y, ldy, (float*)workspace, (int)M, (int)N, rows_per_split, sg)
   if (nb == 1) L(1); else if (nb == 2) L(2); else if (nb == 3) L(3); else L(4);
 #undef L
   LLX_LAUNCH_CHECK("llx_skinny_tn");
-  if (segs) {
-    hipLaunchKernelGGL(skinny_tn_reduce_segs_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, stream, (const float*)workspace, (bf16_t*)out,
-                       nsplit, nb * 16, (int)N, scale, accumulate, sg);
-    LLX_LAUNCH_CHECK("llx_skinny_tn(reduce segments)");
-    return LLX_OK;
-  }
-  hipLaunchKernelGGL(skinny_tn_reduce_kernel, dim3((unsigned)cdiv64(R * N, 256)), dim3(256), 0, stream, (const float*)workspace, (bf16_t*)out,
-                     out_ld, nsplit, nb * 16, (int)R, (int)N, scale, transpose_out, accumulate);
-  LLX_LAUNCH_CHECK("llx_skinny_tn(reduce)");
   return LLX_OK;
+}
+
+// second stage of up to TN_MANY products in ONE launch (the four adapter gradients of a transformer block): blockIdx.y picks the product.
+#define TN_MANY 4
+struct TnRed { const float* partial; bf16_t* out; int64_t out_ld, total; int nsplit, RP, R, N, transpose_out, accumulate, use_segs; float scale; TnSegs sg; };
+struct TnRedMany { TnRed d[TN_MANY]; };
+
+__global__ void skinny_tn_reduce_many_kernel(const TnRedMany m) {
+  const TnRed& d = m.d[blockIdx.y];
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= d.total) return;
+  int r, n;
+  bf16_t* dst;
+  if (d.use_segs) {
+    int s = 0;
+    for (; s < d.sg.count; ++s) {
+      const int64_t cnt = (int64_t)(d.sg.n_hi[s] - d.sg.n_lo[s]) * (d.sg.r_hi[s] - d.sg.r_lo[s]);
+      if (idx < cnt) break;
+      idx -= cnt;
+    }
+    if (s >= d.sg.count) return;
+    const int rw = d.sg.r_hi[s] - d.sg.r_lo[s];
+    n = d.sg.n_lo[s] + (int)(idx / rw);
+    r = d.sg.r_lo[s] + (int)(idx % rw);
+    dst = d.out + d.sg.off[s] + idx;
+  } else {
+    r = (int)(idx / d.N);
+    n = (int)(idx % d.N);
+    dst = d.transpose_out ? d.out + (int64_t)n * d.out_ld + r : d.out + (int64_t)r * d.out_ld + n;
+  }
+  float sum = 0.f;
+  for (int p = 0; p < d.nsplit; ++p) sum += d.partial[((int64_t)p * d.RP + r) * d.N + n];
+  sum *= d.scale;
+  if (d.accumulate) sum += bf2f(*dst);
+  *dst = f2bf(sum);
+}
+
+// Arrays of length n (<= 4), one entry per product: the workspace its llx_skinny_tn_partial filled, the output and the arguments of
+// llx_skinny_tn (M, N, R give the split count).  segs[i] (nullable host pointer) / seg_count[i] as in llx_skinny_tn.
+extern "C" int llx_skinny_tn_reduce_many(int n, const void* const* workspaces, void* const* outs, const int64_t* out_ld, const int64_t* M,
+                                         const int64_t* N, const int64_t* R, const float* scale, const int* transpose_out, const int* accumulate,
+                                         const int32_t* const* segs, const int* seg_count, hipStream_t stream) {
+  LLX_REQUIRE(n >= 1 && n <= TN_MANY && workspaces && outs && out_ld && M && N && R && scale && transpose_out && accumulate && segs && seg_count,
+              "llx_skinny_tn_reduce_many: bad arguments (1..4 products)");
+  TnRedMany m;
+  int64_t most = 0;
+  for (int i = 0; i < n; ++i) {
+    TnRed& d = m.d[i];
+    LLX_REQUIRE(workspaces[i] && outs[i] && M[i] > 0 && N[i] > 0 && R[i] > 0 && R[i] <= 64, "llx_skinny_tn_reduce_many: bad product %d", i);
+    d.partial = (const float*)workspaces[i]; d.out = (bf16_t*)outs[i]; d.out_ld = out_ld[i];
+    d.nsplit = tn_splits(M[i], N[i]); d.RP = (int)cdiv64(R[i], 16) * 16; d.R = (int)R[i]; d.N = (int)N[i];
+    d.transpose_out = transpose_out[i]; d.accumulate = accumulate[i]; d.scale = scale[i];
+    d.use_segs = segs[i] != nullptr;
+    int64_t total = 0;
+    const int rc = tn_fill_segs(d.sg, segs[i], seg_count[i], N[i], R[i], &total);
+    if (rc != LLX_OK) return rc;
+    d.total = d.use_segs ? total : R[i] * N[i];
+    if (d.total > most) most = d.total;
+  }
+  hipLaunchKernelGGL(skinny_tn_reduce_many_kernel, dim3((unsigned)cdiv64(most, 256), (unsigned)n), dim3(256), 0, stream, m);
+  LLX_LAUNCH_CHECK("llx_skinny_tn_reduce_many");
+  return LLX_OK;
+}
+
+// U: [M, 64] bf16 (row stride 64; columns >= R ignored), Y: [M, N] (row stride ldy).  workspace as above.
+// segs (host pointer, nullable): up to 4 members {n_lo, n_hi, r_lo, r_hi} (n bounds multiples of 256 or N), seg_count of them:
+// only those blocks of the [N, R] product are computed, and member i's block is written transposed-out as a contiguous
+// [n_hi - n_lo, r_hi - r_lo] matrix at out + sum_{j<i} size_j (out_ld and transpose_out are ignored).
+extern "C" int llx_skinny_tn(const void* U, const void* Y, int64_t ldy, void* out, int64_t out_ld, int64_t M, int64_t N, int64_t R,
+                             float scale, int transpose_out, int accumulate, void* workspace, const int32_t* segs, int seg_count,
+                             hipStream_t stream) {
+  LLX_REQUIRE(out, "llx_skinny_tn: null pointer");
+  int rc = llx_skinny_tn_partial(U, Y, ldy, M, N, R, workspace, segs, seg_count, stream);
+  if (rc != LLX_OK) return rc;
+  const void* ws[1] = {workspace};
+  void* outs[1] = {out};
+  return llx_skinny_tn_reduce_many(1, ws, outs, &out_ld, &M, &N, &R, &scale, &transpose_out, &accumulate, &segs, &seg_count, stream);
 }
 
 // ------------------------------------------------------------------------------------------ RMSNorm + NT in one pass

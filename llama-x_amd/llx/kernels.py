@@ -600,10 +600,12 @@ def skinny_nt(x: Tensor, w: Tensor, kranges: Optional[Sequence[int]] = None) -> 
 
 
 def skinny_tn(u: Tensor, y: Tensor, R: int, scale_: float, out: Tensor, transpose_out: bool, accumulate: bool = False,
-              segs: Optional[Sequence[tuple[int, int, int, int]]] = None) -> Tensor:
+              segs: Optional[Sequence[tuple[int, int, int, int]]] = None, pending: Optional[list] = None) -> Tensor:
     """out ([R,N], or [N,R] when transpose_out) (+)= scale * u[:, :R]^T @ y, u [M,64], y [M,N].
     segs: members (n_lo, n_hi, r_lo, r_hi) of a fused group (block-diagonal product): out is then a flat buffer that receives the
-    members' [n, r] blocks one after another, each contiguous."""
+    members' [n, r] blocks one after another, each contiguous.
+    pending: a list - only the first stage (fp32 split partials) is launched and the second stage is appended to it; ``out`` is valid
+    once skinny_tn_flush(pending) has run (one launch for up to 4 products: the adapter gradients of a transformer block)."""
     _chk_bf16(u, y, out)
     M, N = y.shape
     assert u.shape == (M, SK_PAD) and u.is_contiguous() and y.stride(1) == 1 and out.stride(-1) == 1
@@ -615,6 +617,32 @@ def skinny_tn(u: Tensor, y: Tensor, R: int, scale_: float, out: Tensor, transpos
     else:
         assert out.shape == ((N, R) if transpose_out else (R, N))
     ws = torch.empty(_lib().llx_skinny_tn_workspace_bytes(M, N, R), device=y.device, dtype=torch.uint8)
-    L.check(_lib().llx_skinny_tn(L.ptr(u), L.ptr(y), y.stride(0), L.ptr(out), out.stride(0) if out.dim() == 2 else 0, M, N, R, scale_,
-                                 int(transpose_out), int(accumulate), L.ptr(ws), sp, ns, L.stream()), "llx_skinny_tn")
+    out_ld = out.stride(0) if out.dim() == 2 else 0
+    if pending is None:
+        L.check(_lib().llx_skinny_tn(L.ptr(u), L.ptr(y), y.stride(0), L.ptr(out), out_ld, M, N, R, scale_, int(transpose_out), int(accumulate),
+                                     L.ptr(ws), sp, ns, L.stream()), "llx_skinny_tn")
+        return out
+    L.check(_lib().llx_skinny_tn_partial(L.ptr(u), L.ptr(y), y.stride(0), M, N, R, L.ptr(ws), sp, ns, L.stream()), "llx_skinny_tn_partial")
+    pending.append((ws, out, out_ld, M, N, R, scale_, int(transpose_out), int(accumulate), sp, ns))
+    if len(pending) == 4:
+        skinny_tn_flush(pending)
     return out
+
+
+def skinny_tn_flush(pending: list) -> None:
+    """Second stage of every product queued by skinny_tn(..., pending=...) in one launch (at most 4 per launch)."""
+    while pending:
+        chunk, pending[:] = pending[:4], pending[4:]
+        n = len(chunk)
+        WS = (ctypes.c_void_p * n)(*[c[0].data_ptr() for c in chunk])
+        OUT = (ctypes.c_void_p * n)(*[c[1].data_ptr() for c in chunk])
+        LD = (ctypes.c_int64 * n)(*[c[2] for c in chunk])
+        MM = (ctypes.c_int64 * n)(*[c[3] for c in chunk])
+        NN = (ctypes.c_int64 * n)(*[c[4] for c in chunk])
+        RR = (ctypes.c_int64 * n)(*[c[5] for c in chunk])
+        SC = (ctypes.c_float * n)(*[c[6] for c in chunk])
+        TR = (ctypes.c_int * n)(*[c[7] for c in chunk])
+        AC = (ctypes.c_int * n)(*[c[8] for c in chunk])
+        SG = (ctypes.c_void_p * n)(*[ctypes.cast(c[9], ctypes.c_void_p).value if c[9] is not None else None for c in chunk])
+        NS = (ctypes.c_int * n)(*[c[10] for c in chunk])
+        L.check(_lib().llx_skinny_tn_reduce_many(n, WS, OUT, LD, MM, NN, RR, SC, TR, AC, SG, NS, L.stream()), "llx_skinny_tn_reduce_many")

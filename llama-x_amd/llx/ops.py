@@ -375,9 +375,11 @@ class GroupPlan:
         return self._kr or None
 
     def backward(self, dy: Tensor, x: Tensor, saved, needs: Sequence[bool], need_dx: bool, dx_out: Optional[Tensor] = None,
-                 swiglu: Optional[tuple[Tensor, Tensor]] = None):
+                 swiglu: Optional[tuple[Tensor, Tensor]] = None, pending: Optional[list] = None):
         """swiglu = (gate|up activations [M, 2K], dg|du output [M, 2K]): the data gradient of this linear is the gradient of
-        silu(g)*u, and the dgrad GEMM applies the SwiGLU backward in its epilogue (returns the dg|du tensor instead of dx)."""
+        silu(g)*u, and the dgrad GEMM applies the SwiGLU backward in its epilogue (returns the dg|du tensor instead of dx).
+        pending: the second stage of the adapter-gradient products is queued there instead of launched (K.skinny_tn_flush: the block's
+        backward runs the second stages of its two groups - four products - in one launch before it returns the gradients)."""
         if not self.fused:
             grads, dx, first = [], None, True
             ni = 0
@@ -415,19 +417,19 @@ class GroupPlan:
             segs = self._tn_segs()
             if segs is not None:  # each member's dB lands in its own contiguous block of one flat buffer: no slicing copies
                 flat = torch.empty(sum((b - a) * (d - c_) for a, b, c_, d in segs), device=dy.device, dtype=BF16)
-                K.skinny_tn(t, dy, self.R, self.scale, flat, transpose_out=True, segs=segs)
+                K.skinny_tn(t, dy, self.R, self.scale, flat, transpose_out=True, segs=segs, pending=pending)
                 gB_views, off = [], 0
                 for m_, (a, b, c_, d) in zip([m for m in self.members if m.rank > 0], segs):
                     gB_views.append(flat[off : off + (b - a) * (d - c_)].view(b - a, d - c_))
                     off += (b - a) * (d - c_)
             else:
                 gBt = torch.empty(self.N, self.R, device=dy.device, dtype=BF16)
-                K.skinny_tn(t, dy, self.R, self.scale, gBt, transpose_out=True)
+                K.skinny_tn(t, dy, self.R, self.scale, gBt, transpose_out=True)  # (sliced below: needs the finished product)
         if self.R > 0:  # u = dy.B, then dA = s u^T.x
             u = K.skinny_nt(dy, bT, self._kranges())  # [M,64]: column block i = dy_i @ B_i
             if need_a:
                 gA = torch.empty(self.R, self.K, device=dy.device, dtype=BF16)
-                K.skinny_tn(u, x, self.R, self.scale, gA, transpose_out=False)
+                K.skinny_tn(u, x, self.R, self.scale, gA, transpose_out=False, pending=pending)
         dx = None
         if need_dx:
             g = K.scale(dy, colscale=self.scale_cat()) if self.int8 else dy  # (g * scale) rounded (subclasses/int8.py:127)
@@ -617,8 +619,9 @@ class AttnBlockFn(Function):
         needs = list(ctx.needs_input_grad[4:])
         n_qkv = len(meta.qkv.tensors())
         nqkv, no = needs[:n_qkv], needs[n_qkv:]
+        pend = [] if _BATCH_TN_REDUCE else None  # second stages of the four adapter-gradient products of this block: one launch at the end
         # wo
-        do2, g_o = meta.wo.backward(dy2, o.view(B * S, H * hd), to, no, True)
+        do2, g_o = meta.wo.backward(dy2, o.view(B * S, H * hd), to, no, True, pending=pend)
         # attention
         W = (H + 2 * KVH) * hd
         dqkv = torch.empty(B, S, W, device=x.device, dtype=BF16)
@@ -637,7 +640,9 @@ class AttnBlockFn(Function):
         need_dx = ctx.needs_input_grad[0]
         need_dxn = need_dx or (meta.fuse_norm and ctx.needs_input_grad[2])  # the norm weight gradient needs d(xn) too
         dxn = torch.empty(B * S, D, device=x.device, dtype=BF16) if need_dxn else None
-        _, g_qkv = meta.qkv.backward(d2, xn, tqkv, nqkv, need_dxn, dxn)
+        _, g_qkv = meta.qkv.backward(d2, xn, tqkv, nqkv, need_dxn, dxn, pending=pend)
+        if pend:
+            K.skinny_tn_flush(pend)
         dx = dnw = None
         if meta.fuse_norm:
             if need_dxn:
@@ -653,6 +658,7 @@ class AttnBlockFn(Function):
 # MLP residual branch:  [x +] w2( silu(w1 xn) * w3 xn ),  xn = [rmsnorm(x)]
 # =================================================================================================
 _FUSE_SWIGLU_FWD = os.environ.get("LLX_FUSE_SWIGLU_FWD", "1") != "0"  # A/B knob: 0 = stand-alone swiglu_fwd kernel
+_BATCH_TN_REDUCE = os.environ.get("LLX_BATCH_TN_REDUCE", "1") != "0"  # A/B knob: 0 = every adapter-gradient product reduces its partials at once
 _FUSE_NORM_SKINNY = os.environ.get("LLX_FUSE_NORM_SKINNY", "1") != "0"  # A/B knob: 0 = RMSNorm, then the stand-alone skinny product
 _FUSE_NORM_QUANT = os.environ.get("LLX_FUSE_NORM_QUANT", "1") != "0"  # A/B knob: 0 = stand-alone activation quantiser after the RMSNorm
 _FUSE_ROPE = os.environ.get("LLX_FUSE_ROPE", "1") != "0"  # A/B knob: 0 = stand-alone rope kernel after the projection / before its dgrad
@@ -704,15 +710,18 @@ class MLPBlockFn(Function):
         n_13 = len(meta.w13.tensors())
         n13, n2 = needs[:n_13], needs[n_13:]
         dgu = torch.empty(T, 2 * I, device=x.device, dtype=BF16)
+        pend = [] if _BATCH_TN_REDUCE else None  # second stages of the four adapter-gradient products of this block: one launch at the end
         if meta.w2.fused:  # dh = dy.W2 (+LoRA) never reaches HBM: the dgrad GEMM's epilogue turns it into dg | du
-            _, g_2 = meta.w2.backward(dy2, h, t2, n2, True, swiglu=(gu, dgu))
+            _, g_2 = meta.w2.backward(dy2, h, t2, n2, True, swiglu=(gu, dgu), pending=pend)
         else:
             dh, g_2 = meta.w2.backward(dy2, h, t2, n2, True)
             K.swiglu_bwd(dh, gu[:, :I], gu[:, I:], dgu[:, :I], dgu[:, I:])
         need_dx = ctx.needs_input_grad[0]
         need_dxn = need_dx or (meta.fuse_norm and ctx.needs_input_grad[1])
         dxn = torch.empty_like(x2) if need_dxn else None
-        _, g_13 = meta.w13.backward(dgu, xn, t13, n13, need_dxn, dxn)
+        _, g_13 = meta.w13.backward(dgu, xn, t13, n13, need_dxn, dxn, pending=pend)
+        if pend:
+            K.skinny_tn_flush(pend)
         dx = dnw = None
         if meta.fuse_norm:
             if need_dxn:
