@@ -163,6 +163,12 @@ def run_workload(args, config: str, device, world: int, rank: int, steps: int, w
     S = seq or args.seq
     model, cfg = build_model(args.model, S, args.rank, device, config, args.trainable)
     trainable = [p for p in model.parameters() if p.requires_grad]
+    if not args.no_arena:
+        # LoRA factors + norm weights in one flat parameter / gradient arena: backward writes the gradients in place, AdamW is one
+        # full-width launch, a data-parallel bucket is a slice (llx/arena.py)
+        from llx.arena import TrainableArena
+
+        trainable = TrainableArena(model).params()
     force_dp = os.environ.get("LLX_FORCE_DP") == "1"  # rehearse the N>1 code path (flat buckets + RCCL) on one GPU
     use_graph = not args.no_graph
     dp = world > 1 or force_dp
@@ -245,6 +251,7 @@ def run_workload(args, config: str, device, world: int, rank: int, steps: int, w
             ids, labels = batch()
             loss = run_model(ids, labels)
             loss.backward()
+            buckets.finish()
             optim.step()
             buckets.zero_grad()
             return loss
@@ -259,6 +266,7 @@ def run_workload(args, config: str, device, world: int, rank: int, steps: int, w
                     for _ in range(2):  # warm caches (fused / transposed weight images, LDS attributes) outside the capture
                         buckets.zero_grad()
                         run_model(ids_buf, labels_buf).backward()
+                        buckets.finish()
                         optim.step()
                 torch.cuda.current_stream().wait_stream(side)
                 buckets.zero_grad()
@@ -266,6 +274,7 @@ def run_workload(args, config: str, device, world: int, rank: int, steps: int, w
                 with torch.cuda.graph(graph):
                     static_loss = run_model(ids_buf, labels_buf)
                     static_loss.backward()
+                    buckets.finish()
                     optim.step()
 
                 def step():
@@ -369,6 +378,7 @@ def main():
                          "scripts' default trainable set (train_metamathqa.py:177-180) - weight gradients of the embedding and the LM head")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a captured hipGraph (single GPU)")
+    ap.add_argument("--no-arena", action="store_true", help="keep the trainable tensors separate (per-tensor AdamW launches; A/B of llx/arena.py)")
     ap.add_argument("--no-extras", action="store_true", help="skip the int8 / audio / packed workloads timed after the headline run (N=1, text only)")
     ap.add_argument("--extra-steps", type=int, default=6, help="timed steps of each extra workload (after 2 warm-up steps)")
     args = ap.parse_args()

@@ -24,6 +24,9 @@ class GradBuckets:
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.active = self.world > 1 or force
+        # llx.arena.TrainableArena: the small trainables already live in one flat gradient buffer that backward writes in place -
+        # their buckets are slices of it (no views to install, no accumulate-add kernels, no memset)
+        self.arena = getattr(model, "_llx_arena", None)
         params = [p for p in model.parameters() if p.requires_grad]
         self._params = params
         if not self.active:
@@ -36,12 +39,13 @@ class GradBuckets:
         if groups is not None:
             seen = {id(p) for g in groups for p in g}
             assert seen == {id(p) for p in params}, "groups must cover exactly the trainable parameters"
-            for g in groups:
-                by_dtype: dict = {}
+            for gi, g in enumerate(groups):
+                by_kind: dict = {}
                 for p in g:
-                    by_dtype.setdefault(p.dtype, []).append(p)
-                self.buckets += [self._make(ps) for ps in by_dtype.values()]
-            self.group_of_bucket = [gi for gi, g in enumerate(groups) for _ in {p.dtype for p in g}]
+                    by_kind.setdefault((p.dtype, self._in_arena(p)), []).append(p)
+                for ps in by_kind.values():
+                    self.buckets.append(self._make(ps))
+                    self.group_of_bucket.append(gi)
         else:
             # backward produces gradients roughly in reverse registration order: bucket 0 = last layers
             params = list(reversed(params))
@@ -49,7 +53,8 @@ class GradBuckets:
             target = (total + n_buckets - 1) // max(1, n_buckets)
             cur, cur_n = [], 0
             for p in params:
-                if cur and (p.dtype != cur[0].dtype or (cur_n + p.numel() > target and len(self.buckets) < n_buckets - 1)):
+                if cur and (p.dtype != cur[0].dtype or self._in_arena(p) != self._in_arena(cur[0])
+                            or (cur_n + p.numel() > target and len(self.buckets) < n_buckets - 1)):
                     self.buckets.append(self._make(cur))
                     cur, cur_n = [], 0
                 cur.append(p)
@@ -65,15 +70,21 @@ class GradBuckets:
                     self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(bi)))
         self.sync_enabled = True  # set False on non-final micro-batches of gradient accumulation
 
+    def _in_arena(self, p) -> bool:
+        return self.arena is not None and self.arena.contains(p)
+
     def _make(self, params):
         dtype, device = params[0].dtype, params[0].device
         assert all(p.dtype == dtype for p in params), "a bucket holds one dtype"
+        if self._in_arena(params[0]):
+            flats = self.arena.ranges(params)  # normally ONE slice: the arena is laid out in layer order
+            return {"params": params, "flat": flats[0], "flats": flats, "pending": len(params), "arena": True}
         flat = torch.zeros(sum(p.numel() for p in params), dtype=dtype, device=device)
         off = 0
         for p in params:
             p.grad = flat[off : off + p.numel()].view_as(p)
             off += p.numel()
-        return {"params": params, "flat": flat, "pending": len(params)}
+        return {"params": params, "flat": flat, "flats": [flat], "pending": len(params), "arena": False}
 
     def _make_hook(self, bi: int):
         def hook(param):
@@ -90,15 +101,20 @@ class GradBuckets:
     def prescale(self, b):
         """flat /= world (sum of means = mean of sums, keeps bf16 range).  Split from the exchange so that it can be captured at the
         end of a backward stage's hipGraph."""
-        if self.world > 1 and not b.get("scaled"):
-            b["flat"].div_(self.world)
+        if not b.get("scaled"):
+            if b["arena"]:
+                self.arena.settle(b["params"])  # gradients that did not land in place (accumulation, foreign producers) join here
+            if self.world > 1:
+                for f in b["flats"]:
+                    f.div_(self.world)
         b["scaled"] = True
 
     def _launch(self, b):
         b["launched"] = True
         self.prescale(b)
         if dist.is_initialized():
-            self._handles.append(dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+            for f in b["flats"]:
+                self._handles.append(dist.all_reduce(f, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
 
     def launch_group(self, gi: int):
         """Start the exchange of every bucket of group `gi` now (asynchronous: RCCL's stream waits for the current stream's tail,
@@ -116,6 +132,8 @@ class GradBuckets:
             for b in self.buckets:
                 if not b.get("launched"):
                     self._launch(b)
+        elif self.arena is not None and not self.active:
+            self.arena.settle()  # single replica: the flat optimizer is the only reader of the arena's gradient buffer
         for h in self._handles:
             h.wait()
         self._handles.clear()
@@ -131,7 +149,11 @@ class GradBuckets:
                 p.grad = None
             return
         for b in self.buckets:
-            b["flat"].zero_()
+            if b["arena"]:
+                for p in b["params"]:
+                    p.grad = None  # the next backward writes the arena slice in place
+            else:
+                b["flat"].zero_()
 
 
 class StagedStep:

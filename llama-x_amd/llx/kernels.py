@@ -93,8 +93,9 @@ def rmsnorm_skinny_nt(x: Tensor, w: Tensor, eps: float, a_cat: Tensor) -> tuple[
     return y.view(x.shape), rstd, t
 
 
-def rmsnorm_bwd(dy: Tensor, x: Tensor, w: Tensor, rstd: Tensor, need_dw: bool, dres: Optional[Tensor] = None) -> tuple[Tensor, Optional[Tensor]]:
-    """dx (+ dres, the gradient coming around the residual connection, joined in the same pass), dw."""
+def rmsnorm_bwd(dy: Tensor, x: Tensor, w: Tensor, rstd: Tensor, need_dw: bool, dres: Optional[Tensor] = None,
+                dw_out: Optional[Tensor] = None) -> tuple[Tensor, Optional[Tensor]]:
+    """dx (+ dres, the gradient coming around the residual connection, joined in the same pass), dw (into dw_out when given)."""
     _chk_bf16(dy, x, w, dres)
     x2, dy2 = _rows2d(x), _rows2d(dy)
     if dy2.stride(0) != dy2.shape[1]:
@@ -103,7 +104,8 @@ def rmsnorm_bwd(dy: Tensor, x: Tensor, w: Tensor, rstd: Tensor, need_dw: bool, d
     dx = torch.empty_like(x2)
     dw = ws = None
     if need_dw:
-        dw = torch.empty(dim, device=x.device, dtype=BF16)
+        dw = dw_out if dw_out is not None else torch.empty(dim, device=x.device, dtype=BF16)
+        assert dw.shape == (dim,) and dw.is_contiguous() and dw.dtype is BF16
         ws = torch.empty(_lib().llx_rmsnorm_bwd_workspace_bytes(rows, dim), device=x.device, dtype=torch.uint8)
     if dres is not None:
         dres = _rows2d(dres)

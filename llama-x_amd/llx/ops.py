@@ -156,10 +156,14 @@ class LinearPlan:
             need_a, need_b = next(ni), next(ni)
             ga = gb = None
             if need_a:
-                ga = torch.empty(self.rank, self.K, device=dy.device, dtype=BF16)
+                ga = _grad_dst([self.lora_a], (self.rank, self.K))
+                if ga is None:
+                    ga = torch.empty(self.rank, self.K, device=dy.device, dtype=BF16)
                 K.skinny_tn(u, x, self.rank, self.scale, ga, transpose_out=False)
             if need_b:
-                gb = torch.empty(self.N, self.rank, device=dy.device, dtype=BF16)
+                gb = _grad_dst([self.lora_b], (self.N, self.rank))
+                if gb is None:
+                    gb = torch.empty(self.N, self.rank, device=dy.device, dtype=BF16)
                 K.skinny_tn(t, dy, self.rank, self.scale, gb, transpose_out=True)
             grads += [ga, gb]
         if self.dora_m is not None:
@@ -416,7 +420,9 @@ class GroupPlan:
         if need_b:
             segs = self._tn_segs()
             if segs is not None:  # each member's dB lands in its own contiguous block of one flat buffer: no slicing copies
-                flat = torch.empty(sum((b - a) * (d - c_) for a, b, c_, d in segs), device=dy.device, dtype=BF16)
+                flat = _grad_dst([m.lora_b for m in self.members if m.rank > 0])  # the arena keeps a group's B factors back to back
+                if flat is None:
+                    flat = torch.empty(sum((b - a) * (d - c_) for a, b, c_, d in segs), device=dy.device, dtype=BF16)
                 K.skinny_tn(t, dy, self.R, self.scale, flat, transpose_out=True, segs=segs, pending=pending)
                 gB_views, off = [], 0
                 for m_, (a, b, c_, d) in zip([m for m in self.members if m.rank > 0], segs):
@@ -428,7 +434,9 @@ class GroupPlan:
         if self.R > 0:  # u = dy.B, then dA = s u^T.x
             u = K.skinny_nt(dy, bT, self._kranges())  # [M,64]: column block i = dy_i @ B_i
             if need_a:
-                gA = torch.empty(self.R, self.K, device=dy.device, dtype=BF16)
+                gA = _grad_dst([m.lora_a for m in self.members if m.rank > 0], (self.R, self.K))  # ... and its A factors
+                if gA is None:
+                    gA = torch.empty(self.R, self.K, device=dy.device, dtype=BF16)
                 K.skinny_tn(u, x, self.R, self.scale, gA, transpose_out=False, pending=pending)
         dx = None
         if need_dx:
@@ -455,6 +463,27 @@ class GroupPlan:
             if m.dora_m is not None:
                 grads.append(gM[no : no + n] if nd[j] else None)
         return dx, grads
+
+
+def _grad_dst(params: Sequence[Optional[Tensor]], shape: Optional[tuple] = None) -> Optional[Tensor]:
+    """Where backward may write the gradients of `params` directly: the slice of the trainable arena's gradient buffer
+    (llx.arena.TrainableArena) that covers them back to back, or None - not in an arena, not adjacent in this order, or one of them
+    already has a ``.grad`` (accumulation micro-step: autograd has to ADD, so the product goes to a fresh buffer)."""
+    g0 = first = end = None
+    for p in params:
+        slot = getattr(p, "_llx_slot", None)
+        if slot is None or p.grad is not None:
+            return None
+        G, off, n = slot
+        if g0 is None:
+            g0, first = G, off
+        elif G is not g0 or off != end:
+            return None
+        end = off + n
+    if g0 is None:
+        return None
+    out = g0[first:end]
+    return out.view(shape) if shape is not None else out
 
 
 def _enc(o, flat: list):
@@ -554,7 +583,7 @@ class RMSNormFn(Function):
     @staticmethod
     def backward(ctx, dy: Tensor):
         x, w, rstd = ctx.saved_tensors
-        dx, dw = K.rmsnorm_bwd(dy.contiguous(), x.contiguous(), w.detach(), rstd, ctx.needs_input_grad[1])
+        dx, dw = K.rmsnorm_bwd(dy.contiguous(), x.contiguous(), w.detach(), rstd, ctx.needs_input_grad[1], dw_out=_grad_dst([w]))
         return dx, dw, None
 
 
@@ -646,7 +675,8 @@ class AttnBlockFn(Function):
         dx = dnw = None
         if meta.fuse_norm:
             if need_dxn:
-                dx, dnw = K.rmsnorm_bwd(dxn, x2, norm_w.detach(), rstd, ctx.needs_input_grad[2], dy2 if (need_dx and meta.fuse_residual) else None)
+                dx, dnw = K.rmsnorm_bwd(dxn, x2, norm_w.detach(), rstd, ctx.needs_input_grad[2], dy2 if (need_dx and meta.fuse_residual) else None,
+                                            dw_out=_grad_dst([norm_w]))
         else:
             dx = dxn
             if need_dx and meta.fuse_residual:
@@ -725,7 +755,8 @@ class MLPBlockFn(Function):
         dx = dnw = None
         if meta.fuse_norm:
             if need_dxn:
-                dx, dnw = K.rmsnorm_bwd(dxn, x2, norm_w.detach(), rstd, ctx.needs_input_grad[1], dy2 if (need_dx and meta.fuse_residual) else None)
+                dx, dnw = K.rmsnorm_bwd(dxn, x2, norm_w.detach(), rstd, ctx.needs_input_grad[1], dy2 if (need_dx and meta.fuse_residual) else None,
+                                            dw_out=_grad_dst([norm_w]))
         else:
             dx = dxn
             if need_dx and meta.fuse_residual:
@@ -760,5 +791,5 @@ class HeadLossFn(Function):
         dx = dnw = None
         if dxn is not None:
             K.scale(dxn, dev_scalar=g32, out=dxn)
-            dx, dnw = K.rmsnorm_bwd(dxn, x2, norm_w.detach(), rstd, ctx.needs_input_grad[1])
+            dx, dnw = K.rmsnorm_bwd(dxn, x2, norm_w.detach(), rstd, ctx.needs_input_grad[1], dw_out=_grad_dst([norm_w]))
         return (dx.view(x.shape) if dx is not None else None, dnw, None, None, None, *grads)

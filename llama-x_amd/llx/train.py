@@ -50,10 +50,24 @@ class Trainer:
         return loss.detach()
 
     # ---- checkpoint wire format of the reference scripts
+    def _arena(self):
+        """The model's trainable arena if the optimizer was built on it (llx.arena.TrainableArena.params())."""
+        arena = getattr(self.model, "_llx_arena", None)
+        if arena is not None and arena.flat and any(p is arena.flat[0] for g in self.optim.param_groups for p in g["params"]):
+            return arena
+        return None
+
     def state_dict(self) -> dict:
-        return dict(step=self.step_idx, model=self.model.state_dict(), optim=self.optim.state_dict())
+        # the optimizer state keeps the reference's per-parameter numbering whether or not the parameters sit in an arena
+        arena = self._arena()
+        optim = arena.optim_state_dict(self.optim) if arena is not None else self.optim.state_dict()
+        return dict(step=self.step_idx, model=self.model.state_dict(), optim=optim)
 
     def load_state_dict(self, ckpt: dict):
         self.step_idx = ckpt["step"]
         self.model.load_state_dict(ckpt["model"])
-        self.optim.load_state_dict(ckpt["optim"])
+        arena = self._arena()
+        if arena is not None:
+            arena.load_optim_state_dict(self.optim, ckpt["optim"])
+        else:
+            self.optim.load_state_dict(ckpt["optim"])

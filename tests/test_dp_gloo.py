@@ -107,6 +107,27 @@ def _worker(rank, world, port, q):
         torch.allclose(seen4[n], dict(ref_model.named_parameters())[n].grad, atol=1e-6) for n in seen4) and len(seen4) == 5
     ok5 = ok5 and torch.allclose(loss4, model(x).sum().detach())
     ok3 = ok3 and ok5
+    # step 6: the same exchange with the small trainables in a flat arena (llx/arena.py): their buckets are slices of the arena's
+    # gradient buffer (no views installed: CPU autograd produces the gradients elsewhere and settle() gathers them), the dense weights
+    # keep classic flat buckets; Trainer accumulates over two micro-batches; the flat optimizer sees the averaged gradients
+    from llx.arena import TrainableArena
+
+    m5 = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.Tanh(), torch.nn.Linear(16, 4), torch.nn.Linear(4, 1))
+    m5.load_state_dict(model.state_dict())
+    arena = TrainableArena(m5)
+    opt5 = torch.optim.SGD(arena.params(), lr=0.0)
+    tr5 = Trainer(m5, opt5, grad_accum=2, n_buckets=2)
+    seen5 = {}
+    opt5.register_step_pre_hook(lambda o, a, k: seen5.update(
+        {n: (arena.grad_view(p) if arena.contains(p) else p.grad).clone() for n, p in m5.named_parameters()}))
+    ok6 = any(b["arena"] for b in tr5.buckets.buckets) and any(not b["arena"] for b in tr5.buckets.buckets)
+    ok6 = ok6 and all(p.grad is None for p in arena.members)
+    for _ in range(2):
+        tr5.step([lambda m: m(x).sum(), lambda m: m(x).sum()])
+        ref_model.zero_grad()
+        (ref_model(data).sum() / world).backward()
+        ok6 = ok6 and len(seen5) == 6 and all(torch.allclose(seen5[n], dict(ref_model.named_parameters())[n].grad, atol=1e-5) for n in seen5)
+    ok3 = ok3 and ok6
     q.put((rank, bool(ok), bool(ok2 and ok3), float(local_only.abs().sum())))
     dist.destroy_process_group()
 
