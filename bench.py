@@ -216,6 +216,7 @@ def run_workload(args, config: str, device, world: int, rank: int, steps: int, w
         return model(ids, labels=labels, block_mask=mask)
 
     ids_buf, labels_buf = batch()
+    info["labelled"] = int((labels_buf != -100).sum())  # positions that carry a label (the leading quarter is a masked prompt: SURVEY 8d C2)
     graph = opt_graph = static_loss = stepper = None
     if dp:
         # N > 1: forward / backward cut into 4 stages of 8 layers (llx.dp.StagedStep): the RCCL all-reduce of a stage's flat gradient
@@ -352,7 +353,8 @@ def _summary(args, r: dict, world: int) -> dict:
          "ms_per_step": round(ms, 2), "p50_step_ms": round(ps[len(ps) // 2], 2), "p10_step_ms": round(ps[len(ps) // 10], 2),
          "p90_step_ms": round(ps[min(len(ps) - 1, (9 * len(ps)) // 10)], 2), "loss": round(r["loss"], 4), "launch": r["launch"],
          "workload": (WORKLOAD_TEXT[r["config"]].format(rank=args.rank, S=r["S"], **r["info"]) if args.model == "llama31_8b"
-                      else f"tiny plumbing config seq={r['S']} ({r['config']})")}
+                      else f"tiny plumbing config seq={r['S']} ({r['config']})"),
+         "labelled_positions": r["info"]["labelled"]}
     g = {k: v for k, v in r["gemm"].items() if v["ms"] > 0}
     if g:
         dominant = max(g, key=lambda k: g[k]["ms"])  # the kernel the step spends most of its time in
@@ -426,7 +428,11 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": sm["workload"] + ("; tok_embeddings / norm / output trainable too (reference default)" if args.trainable == "reference" else ""),
                        "global_batch_tokens": S * world, "seq_len": S, "parallelism": f"dp{world}", "loss": sm["loss"],
-                       "launch": sm["launch"]},
+                       "launch": sm["launch"],
+                       # ignore_index positions (the masked prompt quarter) have no loss term and a zero gradient row: the LM head and the
+                       # loss run over the labelled rows only unless LLX_HEAD_COMPACT=0 (bit-identical gradients, tests/test_model_gpu.py)
+                       "labelled_positions_per_sequence": sm["labelled_positions"],
+                       "lm_head_rows": "labelled only" if os.environ.get("LLX_HEAD_COMPACT", "1") != "0" and args.trainable == "lora" else "all"},
         }
         gf = GF_PER_TOKEN.get(S)
         if gf and args.model == "llama31_8b" and args.config == "text":

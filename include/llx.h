@@ -54,6 +54,12 @@ int llx_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* r
 int llx_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
                      const void* A2, int64_t lda2, const void* B2, int64_t ldb2, int64_t K2, int epilogue, const void* E, int64_t lde,
                      llx_stream_t s);
+/* llx_gemm_nt_bf16 over the first *m_valid rows only (m_valid: DEVICE int32, read by the kernel, so the launch is capturable): row
+ * tiles of 256 that start at or after *m_valid are skipped, rows of C from *m_valid to the end of that tile are computed from
+ * whatever A holds there.  The LM head of modelling/llama.py:216-218 over the positions whose label is not ignore_index. */
+int llx_gemm_nt_bf16_rows(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
+                          const void* A2, int64_t lda2, const void* B2, int64_t ldb2, int64_t K2, int epilogue, const void* E, int64_t lde,
+                          const int32_t* m_valid, llx_stream_t s);
 /* The q|k|v projection with apply_rope (modelling/llama.py:118-125, 63-73) in the epilogue: columns [0, rope_cols) of C (whole
  * 128-wide heads: q then k) are rotated with the fp32 table [>= rope_S, 64, 2]; row m of C is sequence position m % rope_S.
  * Bit-identical to llx_gemm_nt_bf16(epilogue 0) followed by llx_rope. */
@@ -138,6 +144,22 @@ int llx_embedding_bwd(const int64_t* ids, const void* dy, float* dtable_f32, int
 int64_t llx_ce_workspace_bytes(int64_t T);
 int llx_ce_fwd_bwd(const void* logits, int64_t ld, void* dlogits, int64_t dld, const int64_t* labels, float* loss, void* workspace,
                    int64_t T, int64_t V, llx_stream_t s);
+/* ---- LM-head row compaction.  F.cross_entropy(ignore_index=-100) (modelling/llama.py:216-218, modelling/audio.py:74-76): a position
+ *      whose label is -100 adds nothing to the loss and has a zero gradient row, so norm -> head -> CE -> d hidden only need the
+ *      labelled rows.  They are compacted IN ORDER on the device; the count never visits the host (hipGraph-capturable):
+ *        llx_head_compact_index: idx[j] = position of the j-th labelled row (-1 for j >= count), inv[i] = j or -1,
+ *                                labels_c[j] = labels[idx[j]] (-100 beyond), count[0] = number of labelled rows
+ *        llx_gather_rows:        dst[j] = src[idx[j]] (j < count); zero rows up to the next multiple of 256; later rows untouched
+ *        llx_gemm_nt_bf16_rows / llx_ce_fwd_bwd_rows: the head GEMMs / the loss over the compacted rows (rows = count)
+ *        llx_scatter_rows:       dst[i] = bf16(scale[0] * src[inv[i]]) where inv[i] >= 0, zero rows elsewhere
+ *      Loss and every gradient equal the uncompacted computation (same per-row arithmetic; the loss sums the same row terms). */
+int llx_head_compact_index(const int64_t* labels, int32_t* idx, int32_t* inv, int64_t* labels_c, int32_t* count, int64_t T, llx_stream_t s);
+int llx_gather_rows(const void* src, int64_t ld_src, const int32_t* idx, const int32_t* count, void* dst, int64_t ld_dst, int64_t T, int64_t D,
+                    llx_stream_t s);
+int llx_scatter_rows(const void* src, int64_t ld_src, const int32_t* inv, const float* scale /* nullable */, void* dst, int64_t ld_dst,
+                     int64_t T, int64_t D, llx_stream_t s);
+int llx_ce_fwd_bwd_rows(const void* logits, int64_t ld, void* dlogits, int64_t dld, const int64_t* labels, float* loss, void* workspace,
+                        int64_t T, int64_t V, const int32_t* rows, llx_stream_t s);
 
 /* ---- LoRA skinny contractions (modelling/lora.py:43 and its autograd): T = X.W^T -> [M,64] zero padded;
  *      G = s * U^T.Y with fp32 split partials (deterministic). --------------------------------------------------- */

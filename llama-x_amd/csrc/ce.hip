@@ -19,9 +19,13 @@ __global__ void ce_count_kernel(const int64_t* __restrict__ labels, float* __res
 // logits / dlogits carry no __restrict__: the caller passes the same buffer for both (in-place gradient).
 __global__ __launch_bounds__(CE_THREADS) void ce_row_kernel(const bf16_t* logits, bf16_t* dlogits, int64_t ld,
                                                              int64_t dld, const int64_t* __restrict__ labels, float* __restrict__ row_loss,
-                                                             const float* __restrict__ inv_count, int V) {
+                                                             const float* __restrict__ inv_count, int V, const int32_t* __restrict__ rows_dyn) {
   __shared__ float red[16];
   const int64_t t = blockIdx.x;
+  if (rows_dyn != nullptr && t >= ((rows_dyn[0] + 255) & ~255)) {  // compacted rows: nothing reads past the last row tile of the GEMMs
+    if (threadIdx.x == 0) row_loss[t] = 0.f;
+    return;
+  }
   const bf16_t* x = logits + t * ld;
   const int64_t label = labels[t];
   const bool valid = label != -100;
@@ -86,8 +90,8 @@ __global__ void ce_reduce_kernel(const float* __restrict__ row_loss, const float
 // workspace: (T + 2) floats: [0] 1/n_valid, [1] n_valid, [2..] per-row losses.  loss: 1 float (device).
 extern "C" int64_t llx_ce_workspace_bytes(int64_t T) { return (T + 2) * 4; }
 
-extern "C" int llx_ce_fwd_bwd(const void* logits, int64_t ld, void* dlogits, int64_t dld, const int64_t* labels, float* loss, void* workspace,
-                              int64_t T, int64_t V, hipStream_t stream) {
+static int ce_fwd_bwd_impl(const void* logits, int64_t ld, void* dlogits, int64_t dld, const int64_t* labels, float* loss, void* workspace,
+                           int64_t T, int64_t V, const int32_t* rows_dyn, hipStream_t stream) {
   LLX_REQUIRE(logits && labels && loss && workspace, "llx_ce_fwd_bwd: null pointer");
   LLX_REQUIRE(V % 8 == 0 && ld % 8 == 0 && dld % 8 == 0, "llx_ce_fwd_bwd: V and row strides must be multiples of 8");
   LLX_REQUIRE(T > 0 && V > 0 && V < (1 << 30), "llx_ce_fwd_bwd: bad sizes");
@@ -95,9 +99,128 @@ extern "C" int llx_ce_fwd_bwd(const void* logits, int64_t ld, void* dlogits, int
   hipLaunchKernelGGL(ce_count_kernel, dim3(1), dim3(1024), 0, stream, labels, ws, T);
   LLX_LAUNCH_CHECK("llx_ce_fwd_bwd(count)");
   hipLaunchKernelGGL(ce_row_kernel, dim3((unsigned)T), dim3(CE_THREADS), 0, stream, (const bf16_t*)logits, (bf16_t*)dlogits, ld, dld, labels,
-                     ws + 2, ws, (int)V);
+                     ws + 2, ws, (int)V, rows_dyn);
   LLX_LAUNCH_CHECK("llx_ce_fwd_bwd(rows)");
   hipLaunchKernelGGL(ce_reduce_kernel, dim3(1), dim3(1024), 0, stream, ws + 2, ws, loss, T);
   LLX_LAUNCH_CHECK("llx_ce_fwd_bwd(reduce)");
+  return LLX_OK;
+}
+
+extern "C" int llx_ce_fwd_bwd(const void* logits, int64_t ld, void* dlogits, int64_t dld, const int64_t* labels, float* loss, void* workspace,
+                              int64_t T, int64_t V, hipStream_t stream) {
+  return ce_fwd_bwd_impl(logits, ld, dlogits, dld, labels, loss, workspace, T, V, nullptr, stream);
+}
+
+// As llx_ce_fwd_bwd over COMPACTED rows (llx_head_compact_index): the labelled rows come first, *rows (device int32) is their number;
+// rows past the 256-row tile that holds the last labelled row are neither read nor written (the row-limited GEMMs never touch them).
+extern "C" int llx_ce_fwd_bwd_rows(const void* logits, int64_t ld, void* dlogits, int64_t dld, const int64_t* labels, float* loss,
+                                   void* workspace, int64_t T, int64_t V, const int32_t* rows, hipStream_t stream) {
+  LLX_REQUIRE(rows && (uintptr_t)rows % 4 == 0, "llx_ce_fwd_bwd_rows: rows must be a device int32 pointer");
+  return ce_fwd_bwd_impl(logits, ld, dlogits, dld, labels, loss, workspace, T, V, rows, stream);
+}
+
+// ------------------------------------------------------------------------------------------ LM-head row compaction
+// F.cross_entropy(ignore_index=-100) (modelling/llama.py:216-218): a position whose label is -100 adds nothing to the loss and has a
+// zero gradient row, so the head's two GEMMs (logits, d hidden) only need the labelled rows.  The rows are compacted in order on the
+// device (count, index and inverse index stay in device memory: no host round trip, capturable):
+//   idx[j] = position of the j-th labelled row (-1 for j >= count), inv[i] = j or -1, labels_c[j] = labels[idx[j]] (-100 beyond), count[0]
+__global__ __launch_bounds__(1024) void head_compact_index_kernel(const int64_t* __restrict__ labels, int32_t* __restrict__ idx,
+                                                                   int32_t* __restrict__ inv, int64_t* __restrict__ labels_c,
+                                                                   int32_t* __restrict__ count, int T) {
+  __shared__ int wsum[16];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  int base = 0;
+  for (int c0 = 0; c0 < T; c0 += 1024) {
+    const int i = c0 + threadIdx.x;
+    const int64_t lab = i < T ? labels[i] : -100;
+    const bool v = lab != -100;
+    const unsigned long long m = __ballot(v);
+    const int pre = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) wsum[w] = __popcll(m);
+    __syncthreads();
+    int woff = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int sk = wsum[k];
+      woff += k < w ? sk : 0;
+      tot += sk;
+    }
+    if (i < T) {
+      if (v) {
+        const int j = base + woff + pre;
+        idx[j] = i;
+        inv[i] = j;
+        labels_c[j] = lab;
+      } else {
+        inv[i] = -1;
+      }
+    }
+    base += tot;
+    __syncthreads();
+  }
+  for (int j = base + threadIdx.x; j < T; j += 1024) {
+    idx[j] = -1;
+    labels_c[j] = -100;
+  }
+  if (threadIdx.x == 0) count[0] = base;
+}
+
+extern "C" int llx_head_compact_index(const int64_t* labels, int32_t* idx, int32_t* inv, int64_t* labels_c, int32_t* count, int64_t T,
+                                      hipStream_t stream) {
+  LLX_REQUIRE(labels && idx && inv && labels_c && count, "llx_head_compact_index: null pointer");
+  LLX_REQUIRE(T > 0 && T < (1 << 30), "llx_head_compact_index: bad T");
+  hipLaunchKernelGGL(head_compact_index_kernel, dim3(1), dim3(1024), 0, stream, labels, idx, inv, labels_c, count, (int)T);
+  LLX_LAUNCH_CHECK("llx_head_compact_index");
+  return LLX_OK;
+}
+
+// dst[j] = src[idx[j]] for j < count; zero rows up to the end of the 256-row tile of the last labelled row; later rows untouched
+__global__ __launch_bounds__(256) void gather_rows_kernel(const bf16_t* __restrict__ src, int64_t lds_, const int32_t* __restrict__ idx,
+                                                          const int32_t* __restrict__ count, bf16_t* __restrict__ dst, int64_t ldd, int D) {
+  const int j = blockIdx.x, cnt = count[0];
+  if (j >= ((cnt + 255) & ~255)) return;
+  const int i = j < cnt ? idx[j] : -1;
+  for (int c = threadIdx.x; c < (D >> 3); c += 256) {
+    u32x4_t v = {0u, 0u, 0u, 0u};
+    if (i >= 0) v = *reinterpret_cast<const u32x4_t*>(src + (int64_t)i * lds_ + c * 8);
+    *reinterpret_cast<u32x4_t*>(dst + (int64_t)j * ldd + c * 8) = v;
+  }
+}
+
+extern "C" int llx_gather_rows(const void* src, int64_t ld_src, const int32_t* idx, const int32_t* count, void* dst, int64_t ld_dst,
+                               int64_t T, int64_t D, hipStream_t stream) {
+  LLX_REQUIRE(src && idx && count && dst, "llx_gather_rows: null pointer");
+  LLX_REQUIRE(T > 0 && D > 0 && D % 8 == 0 && ld_src % 8 == 0 && ld_dst % 8 == 0 && ((uintptr_t)src | (uintptr_t)dst) % 16 == 0,
+              "llx_gather_rows: D and the row strides must be multiples of 8, pointers 16-byte aligned");
+  hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)T), dim3(256), 0, stream, (const bf16_t*)src, ld_src, idx, count, (bf16_t*)dst, ld_dst, (int)D);
+  LLX_LAUNCH_CHECK("llx_gather_rows");
+  return LLX_OK;
+}
+
+// dst[i] = bf16(scale[0] * src[inv[i]]) where inv[i] >= 0, zero rows elsewhere (scale: nullable device float = the incoming d loss)
+__global__ __launch_bounds__(256) void scatter_rows_kernel(const bf16_t* __restrict__ src, int64_t lds_, const int32_t* __restrict__ inv,
+                                                           const float* __restrict__ scale, bf16_t* __restrict__ dst, int64_t ldd, int D) {
+  const int i = blockIdx.x, j = inv[i];
+  const float s = scale ? scale[0] : 1.f;
+  for (int c = threadIdx.x; c < (D >> 3); c += 256) {
+    u32x4_t v = {0u, 0u, 0u, 0u};
+    if (j >= 0) {
+      v = *reinterpret_cast<const u32x4_t*>(src + (int64_t)j * lds_ + c * 8);
+      if (scale) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = pack_bf2(bflo(v[e]) * s, bfhi(v[e]) * s);
+      }
+    }
+    *reinterpret_cast<u32x4_t*>(dst + (int64_t)i * ldd + c * 8) = v;
+  }
+}
+
+extern "C" int llx_scatter_rows(const void* src, int64_t ld_src, const int32_t* inv, const float* scale, void* dst, int64_t ld_dst, int64_t T,
+                                int64_t D, hipStream_t stream) {
+  LLX_REQUIRE(src && inv && dst, "llx_scatter_rows: null pointer");
+  LLX_REQUIRE(T > 0 && D > 0 && D % 8 == 0 && ld_src % 8 == 0 && ld_dst % 8 == 0 && ((uintptr_t)src | (uintptr_t)dst) % 16 == 0,
+              "llx_scatter_rows: D and the row strides must be multiples of 8, pointers 16-byte aligned");
+  hipLaunchKernelGGL(scatter_rows_kernel, dim3((unsigned)T), dim3(256), 0, stream, (const bf16_t*)src, ld_src, inv, scale, (bf16_t*)dst, ld_dst, (int)D);
+  LLX_LAUNCH_CHECK("llx_scatter_rows");
   return LLX_OK;
 }

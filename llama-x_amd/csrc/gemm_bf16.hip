@@ -38,6 +38,7 @@ struct GemmArgs {
   const bf16_t* sa; const bf16_t* sb;  // int8 kernel: A_scale_rowwise[M], B_scale_colwise[N] (E / lde stay free for the epilogue)
   const float* rope;       // EPI_ROPE: fp32 table [>= rope_S, 64, 2]; row m sits at position m % rope_S
   int rope_S, rope_cols;   //           columns [0, rope_cols) (whole 128-wide heads) are rotated
+  const int* m_valid;      // nullable device int32: row tiles that start at or after *m_valid return at once (llx_gemm_nt_bf16_rows)
 };
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -66,8 +67,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const GemmArgs g) {
   const int wm = wave / WNG, wn = wave % WNG;
 
   // ---- block -> tile: XCD-contiguous chunks (bijective remap), then 4-row groups for L2 panel reuse.
-  const int nwg = g.grid_m * g.grid_n;
+  // row-limited launch (llx_gemm_nt_bf16_rows): the tile space shrinks to the row tiles that hold wanted rows BEFORE the XCD remap, so
+  // the surviving tiles stay spread over all eight XCDs (cutting whole row groups off the static map would idle the XCDs that own them)
+  int grid_m = g.grid_m;
+  if (g.m_valid != nullptr) grid_m = min(grid_m, (*g.m_valid + BM - 1) / BM);
+  const int nwg = grid_m * g.grid_n;
   int bid = blockIdx.x;
+  if (bid >= nwg) return;  // workgroup-uniform, before any barrier
   {
     const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
     bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
@@ -75,7 +81,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const GemmArgs g) {
   const int GROUP_M = 4;
   const int width = GROUP_M * g.grid_n;
   const int group = bid / width;
-  const int gsz = min(g.grid_m - group * GROUP_M, GROUP_M);
+  const int gsz = min(grid_m - group * GROUP_M, GROUP_M);
   const int pid_m = group * GROUP_M + ((bid % width) % gsz);
   const int pid_n = (bid % width) / gsz;
   // EPI_SWIGLU_FWD: B = [W_gate; W_up] (N = 2I rows).  A tile takes 128 gate columns AND the 128 up columns of the same hidden
@@ -495,7 +501,7 @@ static int launch_gemm(const GemmArgs& a, hipStream_t stream) {
 static int gemm_nt_bf16_impl(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M,
                              int64_t N, int64_t K, const void* A2, int64_t lda2, const void* B2, int64_t ldb2, int64_t K2,
                              int epilogue, const void* E, int64_t lde, const float* rope, int64_t rope_S, int64_t rope_cols,
-                             hipStream_t stream) {
+                             hipStream_t stream, const int32_t* m_valid = nullptr) {
   LLX_REQUIRE(A && B && C, "llx_gemm_nt_bf16: null pointer");
   LLX_REQUIRE(M > 0 && N > 0 && K > 0, "llx_gemm_nt_bf16: empty problem M=%lld N=%lld K=%lld", (long long)M, (long long)N, (long long)K);
   LLX_REQUIRE(K % BK == 0 && K2 % BK == 0, "llx_gemm_nt_bf16: K=%lld and K2=%lld must be multiples of 64", (long long)K, (long long)K2);
@@ -520,6 +526,7 @@ static int gemm_nt_bf16_impl(const void* A, int64_t lda, const void* B, int64_t 
   a.col0 = 0; a.col_end = (int)N;
   a.rope = rope; a.rope_S = (int)rope_S; a.rope_cols = (int)rope_cols;
   a.sa = nullptr; a.sb = nullptr;
+  a.m_valid = m_valid;
   switch (epilogue) {
     case EPI_NONE: return launch_gemm<EPI_NONE>(a, stream);
     case EPI_RESIDUAL: return launch_gemm<EPI_RESIDUAL>(a, stream);
@@ -541,6 +548,18 @@ extern "C" int llx_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64
                                 int epilogue, const void* E, int64_t lde, hipStream_t stream) {
   LLX_REQUIRE(epilogue != EPI_ROPE, "llx_gemm_nt_bf16: the RoPE epilogue is llx_gemm_nt_bf16_rope");
   return gemm_nt_bf16_impl(A, lda, B, ldb, C, ldc, M, N, K, A2, lda2, B2, ldb2, K2, epilogue, E, lde, nullptr, 0, 0, stream);
+}
+
+// llx_gemm_nt_bf16 over the FIRST *m_valid rows only (m_valid: device int32, read by the kernel - the count never visits the host, so
+// the launch stays capturable in a hipGraph): row tiles (256 rows) that start at or after *m_valid return at once; rows of C from
+// *m_valid up to the end of its tile are computed from whatever A holds there, later rows are left untouched.  Used for the LM head
+// over the positions whose label is not ignore_index (modelling/llama.py:216-218: ignored positions contribute neither loss nor gradient).
+extern "C" int llx_gemm_nt_bf16_rows(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M,
+                                     int64_t N, int64_t K, const void* A2, int64_t lda2, const void* B2, int64_t ldb2, int64_t K2,
+                                     int epilogue, const void* E, int64_t lde, const int32_t* m_valid, hipStream_t stream) {
+  LLX_REQUIRE(epilogue != EPI_ROPE, "llx_gemm_nt_bf16_rows: the RoPE epilogue is llx_gemm_nt_bf16_rope");
+  LLX_REQUIRE(m_valid && (uintptr_t)m_valid % 4 == 0, "llx_gemm_nt_bf16_rows: m_valid must be a device int32 pointer");
+  return gemm_nt_bf16_impl(A, lda, B, ldb, C, ldc, M, N, K, A2, lda2, B2, ldb2, K2, epilogue, E, lde, nullptr, 0, 0, stream, m_valid);
 }
 
 // The q|k|v projection with apply_rope in the epilogue (modelling/llama.py:118-125): as llx_gemm_nt_bf16 with epilogue 0, then
@@ -571,6 +590,7 @@ extern "C" int llx_int8_mm_dequant(const void* A, int64_t lda, const void* B, in
   a.grid_m = (int)cdiv64(M, BM); a.grid_n = (int)cdiv64(N, BN);
   a.col0 = 0; a.col_end = (int)N;
   a.rope = nullptr; a.rope_S = 0; a.rope_cols = 0;
+  a.m_valid = nullptr;
   return launch_gemm<EPI_ROWCOLSCALE, true>(a, stream);
 }
 
@@ -605,6 +625,7 @@ extern "C" int llx_int8_mm_dequant_ext(const void* A, int64_t lda, const void* B
   a.grid_m = (int)cdiv64(M, BM); a.grid_n = (int)cdiv64(N, BN);
   a.col0 = 0; a.col_end = (int)N;
   a.rope = rope_table; a.rope_S = (int)rope_S; a.rope_cols = (int)rope_cols;
+  a.m_valid = nullptr;
   switch (epilogue) {
     case EPI_RESIDUAL: return launch_gemm<EPI_RESIDUAL, true>(a, stream);
     case EPI_ROPE: return launch_gemm<EPI_ROPE, true>(a, stream);

@@ -65,6 +65,10 @@ SIGNATURES: dict[str, tuple] = {
     "llx_colscale_bias": (c_int, [_P, _L, _P, _L, _P, _P, _L, _L, _P]),
     "llx_ce_workspace_bytes": (c_int64, [_L]),
     "llx_ce_fwd_bwd": (c_int, [_P, _L, _P, _L, _P, _P, _P, _L, _L, _P]),
+    "llx_ce_fwd_bwd_rows": (c_int, [_P, _L, _P, _L, _P, _P, _P, _L, _L, _P, _P]),
+    "llx_head_compact_index": (c_int, [_P, _P, _P, _P, _P, _L, _P]),
+    "llx_gather_rows": (c_int, [_P, _L, _P, _P, _P, _L, _L, _L, _P]),
+    "llx_scatter_rows": (c_int, [_P, _L, _P, _P, _P, _L, _L, _L, _P]),
     "llx_skinny_nt": (c_int, [_P, _L, _P, _L, _P, _L, _L, _L, _P, _P]),
     "llx_rmsnorm_skinny_nt": (c_int, [_P, _P, _P, _L, _P, _P, _P, _L, _L, _L, _F, _P]),
     "llx_skinny_tn_workspace_bytes": (c_int64, [_L, _L, _L]),
@@ -72,6 +76,7 @@ SIGNATURES: dict[str, tuple] = {
     "llx_skinny_tn_partial": (c_int, [_P, _P, _L, _L, _L, _L, _P, _P, _I, _P]),
     "llx_skinny_tn_reduce_many": (c_int, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "llx_gemm_nt_bf16": (c_int, [_P, _L, _P, _L, _P, _L, _L, _L, _L, _P, _L, _P, _L, _L, _I, _P, _L, _P]),
+    "llx_gemm_nt_bf16_rows": (c_int, [_P, _L, _P, _L, _P, _L, _L, _L, _L, _P, _L, _P, _L, _L, _I, _P, _L, _P, _P]),
     "llx_gemm_tn_bf16": (c_int, [_P, _L, _P, _L, _P, _L, _L, _L, _L, _P]),
     "llx_gemm_nt_bf16_rope": (c_int, [_P, _L, _P, _L, _P, _L, _L, _L, _L, _P, _L, _P, _L, _L, _P, _L, _L, _P]),
 }

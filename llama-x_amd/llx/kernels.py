@@ -118,8 +118,10 @@ def rmsnorm_bwd(dy: Tensor, x: Tensor, w: Tensor, rstd: Tensor, need_dw: bool, d
 # ------------------------------------------------------------------------------------------------- gemm
 def gemm_nt(a: Tensor, b: Tensor, *, out: Optional[Tensor] = None, a2: Optional[Tensor] = None, b2: Optional[Tensor] = None,
             epilogue: int = EPI_NONE, e: Optional[Tensor] = None, rope: Optional[tuple[Tensor, int, int]] = None,
-            k2_eff: Optional[float] = None) -> Tensor:
+            k2_eff: Optional[float] = None, m_valid: Optional[Tensor] = None, m_expect: Optional[float] = None) -> Tensor:
     """out[M,N] = a[M,K] @ b[N,K]^T (+ a2[M,K2] @ b2[N,K2]^T) with a fused epilogue; bf16, fp32 accumulate.
+    m_valid (device int32 scalar): only the first m_valid rows are wanted - row tiles past them are skipped by the kernel (no host sync);
+    m_expect: accounting only, the row count the GEMM trace should book for such a launch.
     rope = (fp32 table [>= S, 64, 2], S, cols): apply_rope on columns [0, cols) of out in the epilogue (row m = position m % S).
     k2_eff: accounting only - the K-extension's true contraction length (LoRA rank; the operands are zero padded to 64 columns and
     block diagonal for fused groups), used by the GEMM trace so that multiplying zeros is not counted as algorithmic work."""
@@ -160,6 +162,11 @@ def gemm_nt(a: Tensor, b: Tensor, *, out: Optional[Tensor] = None, a2: Optional[
         L.check(_lib().llx_gemm_nt_bf16_rope(L.ptr(a), a.stride(0), L.ptr(b), b.stride(0), L.ptr(out), out.stride(0), M, N, K,
                                              L.ptr(a2), a2.stride(0) if a2 is not None else 0, L.ptr(b2), b2.stride(0) if b2 is not None else 0, K2,
                                              L.ptr(table), rs, rc, L.stream()), "llx_gemm_nt_bf16_rope")
+    elif m_valid is not None:
+        assert m_valid.dtype is torch.int32 and m_valid.numel() == 1 and m_valid.device == a.device
+        L.check(_lib().llx_gemm_nt_bf16_rows(L.ptr(a), a.stride(0), L.ptr(b), b.stride(0), L.ptr(out), out.stride(0), M, N, K,
+                                             L.ptr(a2), a2.stride(0) if a2 is not None else 0, L.ptr(b2), b2.stride(0) if b2 is not None else 0, K2,
+                                             epilogue, L.ptr(e), lde, L.ptr(m_valid), L.stream()), "llx_gemm_nt_bf16_rows")
     else:
         L.check(_lib().llx_gemm_nt_bf16(L.ptr(a), a.stride(0), L.ptr(b), b.stride(0), L.ptr(out), out.stride(0), M, N, K,
                                         L.ptr(a2), a2.stride(0) if a2 is not None else 0, L.ptr(b2), b2.stride(0) if b2 is not None else 0, K2,
@@ -167,7 +174,8 @@ def gemm_nt(a: Tensor, b: Tensor, *, out: Optional[Tensor] = None, a2: Optional[
     if ev is not None:
         ev[1].record()
         kk = K + (K2 if k2_eff is None else min(float(k2_eff), K2))
-        GEMM_TRACE.append((ev[0], ev[1], 2.0 * M * N * kk, 2.0 * (M * kk + N * kk + M * N * (2 if epilogue == EPI_RESIDUAL else 1)), "bf16",
+        Mw = M if m_expect is None else float(m_expect)  # rows actually wanted (row-limited launches: the labelled rows)
+        GEMM_TRACE.append((ev[0], ev[1], 2.0 * Mw * N * kk, 2.0 * (Mw * kk + N * kk + Mw * N * (2 if epilogue == EPI_RESIDUAL else 1)), "bf16",
                            gemm_kernel_launches(M, N, 8 if rope is not None else epilogue)))
     return out
 
@@ -569,8 +577,44 @@ def attn_dense_fwd(q: Tensor, k: Tensor, v: Tensor, mask: Tensor) -> Tensor:
 
 
 # ------------------------------------------------------------------------------------------------- cross entropy
-def ce_fwd_bwd(logits: Tensor, labels: Tensor, write_grad: bool) -> tuple[Tensor, Optional[Tensor]]:
-    """Mean CE over labels != -100.  With write_grad the logits buffer is overwritten by d loss / d logits."""
+def head_compact_index(labels: Tensor) -> tuple[Tensor, Tensor, Tensor, Tensor]:
+    """(idx, inv, labels_c, count) for the labelled rows (labels != -100) in order; everything stays on the device."""
+    L.require_cuda(labels)
+    labels = labels.reshape(-1).contiguous()
+    assert labels.dtype is torch.int64
+    T = labels.numel()
+    idx = torch.empty(T, device=labels.device, dtype=torch.int32)
+    inv = torch.empty(T, device=labels.device, dtype=torch.int32)
+    labels_c = torch.empty(T, device=labels.device, dtype=torch.int64)
+    count = torch.empty(1, device=labels.device, dtype=torch.int32)
+    L.check(_lib().llx_head_compact_index(L.ptr(labels), L.ptr(idx), L.ptr(inv), L.ptr(labels_c), L.ptr(count), T, L.stream()), "llx_head_compact_index")
+    return idx, inv, labels_c, count
+
+
+def gather_rows(src: Tensor, idx: Tensor, count: Tensor) -> Tensor:
+    """dst[j] = src[idx[j]] for j < count (zero rows up to the next multiple of 256, later rows uninitialised)."""
+    _chk_bf16(src)
+    assert src.dim() == 2 and src.stride(1) == 1 and idx.dtype is torch.int32 and idx.numel() == src.shape[0]
+    T, D = src.shape
+    dst = torch.empty(T, D, device=src.device, dtype=BF16)
+    L.check(_lib().llx_gather_rows(L.ptr(src), src.stride(0), L.ptr(idx), L.ptr(count), L.ptr(dst), D, T, D, L.stream()), "llx_gather_rows")
+    return dst
+
+
+def scatter_rows(src: Tensor, inv: Tensor, dev_scalar: Optional[Tensor] = None) -> Tensor:
+    """dst[i] = bf16(dev_scalar * src[inv[i]]) where inv[i] >= 0, zero rows elsewhere."""
+    _chk_bf16(src)
+    assert src.dim() == 2 and src.stride(1) == 1 and inv.dtype is torch.int32 and inv.numel() == src.shape[0]
+    assert dev_scalar is None or (dev_scalar.dtype is torch.float32 and dev_scalar.numel() == 1)
+    T, D = src.shape
+    dst = torch.empty(T, D, device=src.device, dtype=BF16)
+    L.check(_lib().llx_scatter_rows(L.ptr(src), src.stride(0), L.ptr(inv), L.ptr(dev_scalar), L.ptr(dst), D, T, D, L.stream()), "llx_scatter_rows")
+    return dst
+
+
+def ce_fwd_bwd(logits: Tensor, labels: Tensor, write_grad: bool, rows: Optional[Tensor] = None) -> tuple[Tensor, Optional[Tensor]]:
+    """Mean CE over labels != -100.  With write_grad the logits buffer is overwritten by d loss / d logits.
+    rows (device int32): the rows are compacted (head_compact_index) and only the first `rows` (rounded up to 256) exist."""
     _chk_bf16(logits)
     L.require_cuda(labels)
     lg = _rows2d(logits)
@@ -579,8 +623,12 @@ def ce_fwd_bwd(logits: Tensor, labels: Tensor, write_grad: bool) -> tuple[Tensor
     assert labels.dtype is torch.int64 and labels.numel() == T
     loss = torch.empty((), device=logits.device, dtype=torch.float32)
     ws = torch.empty(_lib().llx_ce_workspace_bytes(T), device=logits.device, dtype=torch.uint8)
-    L.check(_lib().llx_ce_fwd_bwd(L.ptr(lg), lg.stride(0), L.ptr(lg) if write_grad else None, lg.stride(0), L.ptr(labels), L.ptr(loss),
-                                  L.ptr(ws), T, V, L.stream()), "llx_ce_fwd_bwd")
+    if rows is not None:
+        L.check(_lib().llx_ce_fwd_bwd_rows(L.ptr(lg), lg.stride(0), L.ptr(lg) if write_grad else None, lg.stride(0), L.ptr(labels), L.ptr(loss),
+                                           L.ptr(ws), T, V, L.ptr(rows), L.stream()), "llx_ce_fwd_bwd_rows")
+    else:
+        L.check(_lib().llx_ce_fwd_bwd(L.ptr(lg), lg.stride(0), L.ptr(lg) if write_grad else None, lg.stride(0), L.ptr(labels), L.ptr(loss),
+                                      L.ptr(ws), T, V, L.stream()), "llx_ce_fwd_bwd")
     return loss, (lg if write_grad else None)
 
 

@@ -690,6 +690,7 @@ class AttnBlockFn(Function):
 _FUSE_SWIGLU_FWD = os.environ.get("LLX_FUSE_SWIGLU_FWD", "1") != "0"  # A/B knob: 0 = stand-alone swiglu_fwd kernel
 _BATCH_TN_REDUCE = os.environ.get("LLX_BATCH_TN_REDUCE", "1") != "0"  # A/B knob: 0 = every adapter-gradient product reduces its partials at once
 _FUSE_NORM_SKINNY = os.environ.get("LLX_FUSE_NORM_SKINNY", "1") != "0"  # A/B knob: 0 = RMSNorm, then the stand-alone skinny product
+_HEAD_COMPACT = os.environ.get("LLX_HEAD_COMPACT", "1") != "0"  # LM head + loss over the labelled rows only (HeadLossFn)
 _FUSE_NORM_QUANT = os.environ.get("LLX_FUSE_NORM_QUANT", "1") != "0"  # A/B knob: 0 = stand-alone activation quantiser after the RMSNorm
 _FUSE_ROPE = os.environ.get("LLX_FUSE_ROPE", "1") != "0"  # A/B knob: 0 = stand-alone rope kernel after the projection / before its dgrad
 
@@ -768,15 +769,33 @@ class MLPBlockFn(Function):
 # final norm + LM head + cross-entropy (modelling/llama.py:216-218)
 # =================================================================================================
 class HeadLossFn(Function):
+    """Labelled-row compaction (default; LLX_HEAD_COMPACT=0 turns it off): F.cross_entropy(ignore_index=-100) gives a position whose
+    label is -100 no loss term and a zero gradient row (modelling/llama.py:216-218), so with a frozen plain head the logits GEMM, the
+    loss and the d-hidden GEMM run over the labelled rows only - gathered in order on the device, the count read by the kernels from
+    device memory (no host sync, capturable), d hidden scattered back with zero rows in between.  Same per-row arithmetic, same loss
+    terms: every gradient is bit-identical to the uncompacted path; an SFT batch with a masked prompt saves that share of the head."""
+
     @staticmethod
     def forward(ctx, x: Tensor, norm_w: Tensor, labels: Tensor, eps: float, plan: LinearPlan, *tensors):
         K.L.require_cuda(x, labels)
         x2 = K._rows2d(x.contiguous())
         xn, rstd = K.rmsnorm_fwd(x2, norm_w.detach(), eps)
-        logits, t = plan.forward(xn)
         need_grad = any(ctx.needs_input_grad)
-        loss, dlogits = K.ce_fwd_bwd(logits, labels, write_grad=need_grad)
         ctx.plan, ctx.eps = plan, eps
+        ctx.compact = (_HEAD_COMPACT and not plan.int8 and plan.rank == 0 and plan.bias is None and plan.dora_m is None
+                       and not any(ctx.needs_input_grad[5:]))
+        if ctx.compact:
+            idx, inv, labels_c, cnt = K.head_compact_index(labels)
+            xc = K.gather_rows(xn, idx, cnt)
+            w = plan.weight.detach()
+            logits = torch.empty(xc.shape[0], w.shape[0], device=x.device, dtype=BF16)
+            ctx.m_expect = float(cnt.item()) if K.GEMM_TRACE is not None else None  # accounting of the traced eager step only
+            K.gemm_nt(xc, w, out=logits, m_valid=cnt, m_expect=ctx.m_expect)
+            loss, dlogits = K.ce_fwd_bwd(logits, labels_c, write_grad=need_grad, rows=cnt)
+            _save(ctx, x, norm_w, x2, None, rstd, dlogits, (inv, cnt))
+            return loss
+        logits, t = plan.forward(xn)
+        loss, dlogits = K.ce_fwd_bwd(logits, labels, write_grad=need_grad)
         _save(ctx, x, norm_w, x2, xn, rstd, dlogits, t)
         return loss
 
@@ -786,6 +805,14 @@ class HeadLossFn(Function):
         x, norm_w, x2, xn, rstd, dlogits, t = _load(ctx)
         needs = ctx.needs_input_grad[5:]
         g32 = gout.detach().to(torch.float32).reshape(1)
+        if ctx.compact:
+            inv, cnt = t
+            dx = dnw = None
+            if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+                dxc = K.gemm_nt(dlogits, weight_t(plan.weight), m_valid=cnt, m_expect=ctx.m_expect)
+                dxn = K.scatter_rows(dxc, inv, g32)  # d loss scales the rows on their way back to their positions
+                dx, dnw = K.rmsnorm_bwd(dxn, x2, norm_w.detach(), rstd, ctx.needs_input_grad[1], dw_out=_grad_dst([norm_w]))
+            return (dx.view(x.shape) if dx is not None else None, dnw, None, None, None, *([None] * len(needs)))
         dxn, grads = plan.backward(dlogits, xn, t, needs, need_dx=ctx.needs_input_grad[0] or ctx.needs_input_grad[1])
         grads = [None if g is None else K.scale(g, dev_scalar=g32) for g in grads]
         dx = dnw = None

@@ -823,3 +823,63 @@ def test_rmsnorm_with_fused_adapter_projection(K, cuda, rows, dim, R):
     torch.testing.assert_close(t1[:, :R].float(), ref, atol=2 ** -8 * ref.abs().max().item(), rtol=2 ** -7)
     torch.testing.assert_close(t1.float(), t0.float(), atol=2 ** -8 * ref.abs().max().item(), rtol=2 ** -7)
     assert torch.equal(t1, K.rmsnorm_skinny_nt(x, w, 1e-5, a)[2])
+
+
+# ------------------------------------------------------------------------------------------------- LM-head row compaction
+@pytest.mark.parametrize("pattern", ["prompt", "scattered", "none_ignored", "one_left", "tile_exact", "all_ignored"])
+def test_head_row_compaction_kernels(K, cuda, pattern):
+    """llx_head_compact_index / llx_gather_rows / llx_gemm_nt_bf16_rows / llx_ce_fwd_bwd_rows / llx_scatter_rows against the uncompacted
+    kernels: same logits rows, same loss terms, bit-identical gradient rows, zero rows where the label is ignore_index."""
+    T, D, V = 1000, 256, 1024
+    g = torch.Generator().manual_seed(5)
+    labels = torch.randint(0, V, (T,), generator=g)
+    if pattern == "prompt":
+        labels[:300] = -100
+        labels[-1] = -100
+    elif pattern == "scattered":
+        labels[torch.rand(T, generator=g) < 0.4] = -100
+    elif pattern == "one_left":
+        labels[:] = -100
+        labels[617] = 5
+    elif pattern == "tile_exact":
+        labels[512:] = -100  # exactly two 256-row tiles
+    elif pattern == "all_ignored":
+        labels[:] = -100
+    x = (torch.randn(T, D, generator=g) * 0.5).bfloat16().to(cuda)
+    w = (torch.randn(V, D, generator=g) * 0.05).bfloat16().to(cuda)
+    lab = labels.to(cuda)
+    idx, inv, lab_c, cnt = K.head_compact_index(lab)
+    pos = torch.nonzero(labels != -100).flatten()
+    n = pos.numel()
+    assert int(cnt.item()) == n
+    assert torch.equal(idx[:n].cpu().long(), pos) and bool((idx[n:] == -1).all())
+    want_inv = torch.full((T,), -1, dtype=torch.int64)
+    want_inv[pos] = torch.arange(n)
+    assert torch.equal(inv.cpu().long(), want_inv)
+    assert torch.equal(lab_c[:n].cpu(), labels[pos]) and bool((lab_c[n:] == -100).all())
+    # gather: labelled rows first, zero rows up to the tile boundary
+    xc = K.gather_rows(x, idx, cnt)
+    assert torch.equal(xc[:n].cpu(), x.cpu()[pos])
+    n_tile = (n + 255) // 256 * 256
+    assert not xc[n : min(n_tile, T)].any()
+    # uncompacted path
+    logits_full = K.gemm_nt(x, w)
+    loss_full, dl_full = K.ce_fwd_bwd(logits_full.clone(), lab, True)
+    dx_full = K.gemm_nt(dl_full, K.transpose(w))
+    # compacted path (the output buffers start as NaN: whatever must not be read is never written either)
+    logits_c = torch.full((T, V), float("nan"), device=cuda, dtype=torch.bfloat16)
+    K.gemm_nt(xc, w, out=logits_c, m_valid=cnt)
+    assert torch.equal(logits_c[:n].cpu(), logits_full.cpu()[pos])
+    assert bool(torch.isnan(logits_c[min(n_tile, T) :]).all())  # row tiles past the labelled rows were skipped
+    loss_c, dl_c = K.ce_fwd_bwd(logits_c, lab_c, True, rows=cnt)
+    assert torch.equal(dl_c[:n].cpu(), dl_full.cpu()[pos]) and not dl_c[n : min(n_tile, T)].any()
+    if n:
+        assert abs(loss_c.item() - loss_full.item()) <= 2e-6 * abs(loss_full.item())
+    else:
+        assert torch.isnan(loss_c) and torch.isnan(loss_full)  # mean over zero rows, as F.cross_entropy
+    dxc = torch.full((T, D), float("nan"), device=cuda, dtype=torch.bfloat16)
+    K.gemm_nt(dl_c, K.transpose(w), out=dxc, m_valid=cnt)
+    gscale = torch.tensor([0.5], device=cuda)
+    dx = K.scatter_rows(dxc, inv, gscale)
+    assert torch.equal(dx.cpu(), K.scale(dx_full, dev_scalar=gscale).cpu())
+    assert not dx.cpu()[labels == -100].any()

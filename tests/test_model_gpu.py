@@ -628,3 +628,38 @@ def test_dora_model_loss_and_grads(cuda):
     for key in ("layers_0_attention_wq_m", "layers_1_feed_forward_w2_m"):  # and the reference's own gradient of m, to bf16 tolerance
         name = key.replace("layers_0_", "layers.0.").replace("layers_1_", "layers.1.").replace("attention_wq_m", "attention.wq.m").replace("feed_forward_w2_m", "feed_forward.w2.m")
         _close(dict(model.named_parameters())[name].grad.float().cpu(), torch.from_numpy(g[key]), 0.08, name + " vs reference golden")
+
+
+@pytest.mark.parametrize("pattern", ["prompt", "scattered"])
+def test_head_compaction_matches_uncompacted_path(cuda, pattern, monkeypatch):
+    """HeadLossFn over the labelled rows only (llx/ops.py, default) against the same model with LLX_HEAD_COMPACT=0: the loss sums the
+    same row terms (different order: 2e-6 relative), every gradient is bit-identical - skipping the ignore_index rows changes nothing
+    the reference computes (modelling/llama.py:216-218: their loss term and gradient row are zero)."""
+    from llx import ops
+
+    p = O.init_params(CFG)
+    p.update(O.init_lora(CFG, 8))
+    pb, _ = bf16_params(p)
+    tokens, labels = _data(2, 256)
+    if pattern == "scattered":
+        labels = torch.roll(tokens, -1, 1).clone()
+        labels[torch.rand(labels.shape, generator=torch.Generator().manual_seed(3)) < 0.5] = -100
+    out = {}
+    for compact in (True, False):
+        monkeypatch.setattr(ops, "_HEAD_COMPACT", compact)
+        model = build_model(CFG, pb, cuda, lora_rank=8)
+        for n, prm in model.named_parameters():
+            prm.requires_grad_("lora_" in n or n.endswith("norm.weight"))
+        loss = model(tokens.to(cuda), labels=labels.to(cuda))
+        loss.backward()
+        out[compact] = (loss.item(), {n: prm.grad.clone() for n, prm in model.named_parameters() if prm.requires_grad})
+    assert abs(out[True][0] - out[False][0]) <= 2e-6 * abs(out[False][0])
+    assert out[True][1].keys() == out[False][1].keys() and len(out[True][1]) > 10
+    for n in out[True][1]:
+        assert torch.equal(out[True][1][n], out[False][1][n]), n
+    # a trainable head needs every row of xn for its weight gradient: the compaction must step aside
+    monkeypatch.setattr(ops, "_HEAD_COMPACT", True)
+    model = build_model(CFG, pb, cuda, lora_rank=8)
+    loss = model(tokens.to(cuda), labels=labels.to(cuda))
+    loss.backward()
+    assert model.output.weight.grad is not None and abs(loss.item() - out[False][0]) <= 2e-6 * abs(out[False][0])
