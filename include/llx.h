@@ -60,6 +60,14 @@ int llx_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, voi
 int llx_gemm_nt_bf16_rows(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
                           const void* A2, int64_t lda2, const void* B2, int64_t ldb2, int64_t K2, int epilogue, const void* E, int64_t lde,
                           const int32_t* m_valid, llx_stream_t s);
+/* Split-K form for a product with few output tiles and a long contraction (d hidden = d logits . W of the LM head, modelling/llama.py:216:
+ * 16 x 16 tiles, K = 128256): partial[s][M][N] fp32 (row stride N) for `splits` equal K ranges from ONE launch over (range, row tile,
+ * column tile); m_valid (nullable) as in llx_gemm_nt_bf16_rows.  K % (64 * splits) == 0.
+ * llx_splitk_combine: out[i] = bf16(scale[0] * bf16(sum_s partial[s][inv ? inv[i] : i])), zero rows where inv[i] < 0 (inv, scale nullable). */
+int llx_gemm_nt_bf16_splitk(const void* A, int64_t lda, const void* B, int64_t ldb, float* partial, int64_t M, int64_t N, int64_t K, int splits,
+                            const int32_t* m_valid, llx_stream_t s);
+int llx_splitk_combine(const float* partial, int splits, int64_t M, int64_t N, const int32_t* inv, const float* scale, void* out, int64_t ld_out,
+                       llx_stream_t s);
 /* The q|k|v projection with apply_rope (modelling/llama.py:118-125, 63-73) in the epilogue: columns [0, rope_cols) of C (whole
  * 128-wide heads: q then k) are rotated with the fp32 table [>= rope_S, 64, 2]; row m of C is sequence position m % rope_S.
  * Bit-identical to llx_gemm_nt_bf16(epilogue 0) followed by llx_rope. */

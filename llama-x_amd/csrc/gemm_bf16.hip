@@ -24,7 +24,7 @@
 // BNT = 128: the "half tile" (256 rows x 128 columns, waves 4 x 2, 64 x 64 per wave) used for the columns a 256-wide grid would leave
 // to a partly empty last round (see gemm_nt_bf16_impl); same LDS stage layout with a half-size B tile.
 
-enum { EPI_NONE = 0, EPI_RESIDUAL = 1, EPI_BIAS = 2, EPI_BIAS_GELU = 3, EPI_COLSCALE = 4, EPI_ROWCOLSCALE = 5, EPI_SWIGLU_BWD = 6, EPI_SWIGLU_FWD = 7, EPI_ROPE = 8 };
+enum { EPI_NONE = 0, EPI_RESIDUAL = 1, EPI_BIAS = 2, EPI_BIAS_GELU = 3, EPI_COLSCALE = 4, EPI_ROWCOLSCALE = 5, EPI_SWIGLU_BWD = 6, EPI_SWIGLU_FWD = 7, EPI_ROPE = 8, EPI_SPLITK = 9 };
 
 struct GemmArgs {
   const bf16_t* A; const bf16_t* B; bf16_t* C;
@@ -39,6 +39,8 @@ struct GemmArgs {
   const float* rope;       // EPI_ROPE: fp32 table [>= rope_S, 64, 2]; row m sits at position m % rope_S
   int rope_S, rope_cols;   //           columns [0, rope_cols) (whole 128-wide heads) are rotated
   const int* m_valid;      // nullable device int32: row tiles that start at or after *m_valid return at once (llx_gemm_nt_bf16_rows)
+  float* C32;              // EPI_SPLITK: fp32 partial products [splits][M][N] (row stride N)
+  int splits;              //             K is cut in `splits` equal ranges; a tile = (range, row tile, column tile)
 };
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -71,13 +73,16 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const GemmArgs g) {
   // the surviving tiles stay spread over all eight XCDs (cutting whole row groups off the static map would idle the XCDs that own them)
   int grid_m = g.grid_m;
   if (g.m_valid != nullptr) grid_m = min(grid_m, (*g.m_valid + BM - 1) / BM);
-  const int nwg = grid_m * g.grid_n;
+  const int nsplit = EPI == EPI_SPLITK ? g.splits : 1;
+  const int nwg = grid_m * g.grid_n * nsplit;
   int bid = blockIdx.x;
   if (bid >= nwg) return;  // workgroup-uniform, before any barrier
   {
     const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
     bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
   }
+  const int split = EPI == EPI_SPLITK ? bid / (grid_m * g.grid_n) : 0;  // K range of this tile (slowest index)
+  if constexpr (EPI == EPI_SPLITK) bid -= split * (grid_m * g.grid_n);
   const int GROUP_M = 4;
   const int width = GROUP_M * g.grid_n;
   const int group = bid / width;
@@ -102,8 +107,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const GemmArgs g) {
     arow[i] = min(m0 + i * 64 + srow, g.M - 1);  // clamp: edge rows re-read a valid row, never stored
     brow[i] = SPLITN ? (i < 2 ? n0 + i * 64 + srow : halfN + n0 + (i - 2) * 64 + srow) : min(n0 + (i % BSI) * 64 + srow, g.col_end - 1);
   }
-  const int nk1 = g.K / TK;
+  const int nk1 = g.K / TK / nsplit;
   const int nk = nk1 + g.K2 / 64;  // K-extension tiles are bf16: 64 elements per 128-byte row
+  const int kofs = split * nk1;    // first K tile of this tile's range (EPI_SPLITK)
 
   // Per-lane source offsets are loop invariant (row * stride + swizzled chunk, 32-bit bytes); per K-tile only the
   // wave-uniform base pointer advances, so the loads need no vector address arithmetic inside the loop.
@@ -117,7 +123,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const GemmArgs g) {
   auto stage_half = [&](int buf, int kt, int half) {
     char* sT = smem + buf * STAGE_BYTES + half * A_TILE_BYTES;
     if (kt < nk1) {
-      const char* base = (const char*)(half ? g.B : g.A) + (int64_t)kt * 128;  // wave-uniform
+      const char* base = (const char*)(half ? g.B : g.A) + (int64_t)(kt + kofs) * 128;  // wave-uniform
 #pragma unroll
       for (int i = 0; i < 4; ++i)
         __builtin_amdgcn_global_load_lds((gbl_void*)(base + (half ? boff[i] : aoff[i])), (lds_void*)(sT + (i * 512 + wave * 64) * 16), 16, 0, 0);
@@ -198,7 +204,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const GemmArgs g) {
       const int np = half ? BSI / 2 : 2;
       char* sT = smem + (kt & 1) * STAGE_BYTES + half * A_TILE_BYTES + hi * np * 8192;
       if (kt < nk1) {
-        const char* base = (const char*)(half ? g.B : g.A) + (int64_t)kt * 128;
+        const char* base = (const char*)(half ? g.B : g.A) + (int64_t)(kt + kofs) * 128;
 #pragma unroll
         for (int j = 0; j < 2; ++j)
           if (j < np)
@@ -333,6 +339,20 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const GemmArgs g) {
     __syncthreads();  // all LDS reads done before the epilogue reuses the stages
   }
 
+  if constexpr (EPI == EPI_SPLITK) {
+    // fp32 partial product of this K range, straight from the accumulators (16 B per lane: 4 consecutive columns of one row)
+    float* P = g.C32 + (int64_t)split * g.M * g.N;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      const int gm = m0 + wm * WR + mi * 16 + frow;
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) {
+        const int gn = n0 + wn * 64 + ni * 16 + fq * 4;
+        if (gm < g.M && gn < g.col_end) *reinterpret_cast<f32x4_t*>(P + (int64_t)gm * g.N + gn) = acc[mi][ni];
+      }
+    }
+    return;
+  }
   // ---- epilogue: acc (C^T fragments: lane owns n = fq*4..+4 for m = frow) -> bf16 -> LDS tile -> coalesced rows.
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
@@ -455,7 +475,7 @@ static int launch_gemm_p(const GemmArgs& a, hipStream_t stream) {
     }
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(a.grid_m * a.grid_n), dim3(512), GEMM_LDS_BYTES, stream, a);
+  hipLaunchKernelGGL(kern, dim3(a.grid_m * a.grid_n * (EPI == EPI_SPLITK ? a.splits : 1)), dim3(512), GEMM_LDS_BYTES, stream, a);
   LLX_LAUNCH_CHECK("llx_gemm_nt_bf16");
   return LLX_OK;
 }
@@ -527,6 +547,7 @@ static int gemm_nt_bf16_impl(const void* A, int64_t lda, const void* B, int64_t 
   a.rope = rope; a.rope_S = (int)rope_S; a.rope_cols = (int)rope_cols;
   a.sa = nullptr; a.sb = nullptr;
   a.m_valid = m_valid;
+  a.C32 = nullptr; a.splits = 1;
   switch (epilogue) {
     case EPI_NONE: return launch_gemm<EPI_NONE>(a, stream);
     case EPI_RESIDUAL: return launch_gemm<EPI_RESIDUAL>(a, stream);
@@ -562,6 +583,70 @@ extern "C" int llx_gemm_nt_bf16_rows(const void* A, int64_t lda, const void* B, 
   return gemm_nt_bf16_impl(A, lda, B, ldb, C, ldc, M, N, K, A2, lda2, B2, ldb2, K2, epilogue, E, lde, nullptr, 0, 0, stream, m_valid);
 }
 
+// Split-K: partial[s][M][N] (fp32, row stride N) = A[:, K_s] . B[:, K_s]^T for the `splits` equal K ranges, ONE launch whose tile
+// space is (range, row tile, column tile): a product with fewer than 256 output tiles but a long contraction (the LM head's
+// d hidden = d logits . W: 16 x 16 tiles, K = 128256 - and only 12 x 16 once the unlabelled rows are skipped) fills the chip and
+// balances its rounds.  llx_splitk_combine sums the ranges.  m_valid (nullable): as llx_gemm_nt_bf16_rows.  K % (64 * splits) == 0.
+extern "C" int llx_gemm_nt_bf16_splitk(const void* A, int64_t lda, const void* B, int64_t ldb, float* partial, int64_t M, int64_t N,
+                                       int64_t K, int splits, const int32_t* m_valid, hipStream_t stream) {
+  LLX_REQUIRE(A && B && partial, "llx_gemm_nt_bf16_splitk: null pointer");
+  LLX_REQUIRE(M > 0 && N > 0 && K > 0 && splits >= 1 && splits <= 16, "llx_gemm_nt_bf16_splitk: bad sizes");
+  LLX_REQUIRE(K % ((int64_t)BK * splits) == 0, "llx_gemm_nt_bf16_splitk: K=%lld must be a multiple of 64 * splits (%d)", (long long)K, splits);
+  LLX_REQUIRE(N % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0, "llx_gemm_nt_bf16_splitk: N and the row strides must be multiples of 8");
+  LLX_REQUIRE(((uintptr_t)A | (uintptr_t)B | (uintptr_t)partial) % 16 == 0, "llx_gemm_nt_bf16_splitk: pointers must be 16-byte aligned");
+  LLX_REQUIRE(M < (1 << 30) && N < (1 << 30) && K < (1 << 30), "llx_gemm_nt_bf16_splitk: dimension too large");
+  LLX_REQUIRE(M * lda * 2 < (int64_t)4294967296 && N * ldb * 2 < (int64_t)4294967296, "llx_gemm_nt_bf16_splitk: operand larger than 4 GiB (32-bit tile offsets)");
+  LLX_REQUIRE(gemm_pipe_mode() == 1, "llx_gemm_nt_bf16_splitk: needs the four-phase main loop (LLX_GEMM_PIPE unset or 1)");
+  LLX_REQUIRE(m_valid == nullptr || (uintptr_t)m_valid % 4 == 0, "llx_gemm_nt_bf16_splitk: m_valid must be a device int32 pointer");
+  GemmArgs a;
+  a.A = (const bf16_t*)A; a.B = (const bf16_t*)B; a.C = nullptr; a.A2 = nullptr; a.B2 = nullptr; a.E = nullptr; a.E2 = nullptr;
+  a.lda = lda; a.ldb = ldb; a.ldc = N; a.lde = 0; a.lda2 = 0; a.ldb2 = 0;
+  a.M = (int)M; a.N = (int)N; a.K = (int)K; a.K2 = 0;
+  a.grid_m = (int)cdiv64(M, BM); a.grid_n = (int)cdiv64(N, BN);
+  a.col0 = 0; a.col_end = (int)N;
+  a.rope = nullptr; a.rope_S = 0; a.rope_cols = 0;
+  a.sa = nullptr; a.sb = nullptr;
+  a.m_valid = m_valid;
+  a.C32 = partial; a.splits = splits;
+  return launch_gemm_p<EPI_SPLITK, false, 1>(a, stream);
+}
+
+// out[i] = bf16(scale[0] * bf16(sum_s partial[s][row(i)][:]))  with row(i) = inv ? inv[i] : i; rows with inv[i] < 0 are zero.
+// (the product is rounded to bf16 first, as the unsplit GEMM would have stored it, then scaled - llx_scale's order)
+__global__ __launch_bounds__(256) void splitk_combine_kernel(const float* __restrict__ partial, int splits, int64_t MN, const int32_t* __restrict__ inv,
+                                                             const float* __restrict__ scale, bf16_t* __restrict__ out, int64_t ldo, int N) {
+  const int i = blockIdx.x, j = inv ? inv[i] : i;
+  const float sc = scale ? scale[0] : 1.f;
+  for (int c = threadIdx.x; c < (N >> 2); c += 256) {
+    u32x2_t o = {0u, 0u};
+    if (j >= 0) {
+      f32x4_t v = *reinterpret_cast<const f32x4_t*>(partial + (int64_t)j * N + c * 4);
+      for (int s2 = 1; s2 < splits; ++s2) {
+        const f32x4_t w = *reinterpret_cast<const f32x4_t*>(partial + s2 * MN + (int64_t)j * N + c * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += w[e];
+      }
+      if (scale) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = bf2f(f2bf(v[e])) * sc;
+      }
+      o[0] = pack_bf2(v[0], v[1]);
+      o[1] = pack_bf2(v[2], v[3]);
+    }
+    *reinterpret_cast<u32x2_t*>(out + (int64_t)i * ldo + c * 4) = o;
+  }
+}
+
+extern "C" int llx_splitk_combine(const float* partial, int splits, int64_t M, int64_t N, const int32_t* inv, const float* scale, void* out,
+                                  int64_t ld_out, hipStream_t stream) {
+  LLX_REQUIRE(partial && out, "llx_splitk_combine: null pointer");
+  LLX_REQUIRE(M > 0 && N > 0 && N % 4 == 0 && ld_out % 4 == 0 && splits >= 1 && splits <= 16, "llx_splitk_combine: bad sizes");
+  LLX_REQUIRE(((uintptr_t)partial) % 16 == 0 && ((uintptr_t)out) % 8 == 0, "llx_splitk_combine: unaligned pointer");
+  hipLaunchKernelGGL(splitk_combine_kernel, dim3((unsigned)M), dim3(256), 0, stream, partial, splits, M * N, inv, scale, (bf16_t*)out, ld_out, (int)N);
+  LLX_LAUNCH_CHECK("llx_splitk_combine");
+  return LLX_OK;
+}
+
 // The q|k|v projection with apply_rope in the epilogue (modelling/llama.py:118-125): as llx_gemm_nt_bf16 with epilogue 0, then
 // columns [0, rope_cols) of C (the q and k heads, 128 wide each) are rotated with the fp32 table [>= rope_S, 64, 2]; row m of C is
 // sequence position m % rope_S.  Bit-identical to the plain GEMM followed by llx_rope.
@@ -591,6 +676,7 @@ extern "C" int llx_int8_mm_dequant(const void* A, int64_t lda, const void* B, in
   a.col0 = 0; a.col_end = (int)N;
   a.rope = nullptr; a.rope_S = 0; a.rope_cols = 0;
   a.m_valid = nullptr;
+  a.C32 = nullptr; a.splits = 1;
   return launch_gemm<EPI_ROWCOLSCALE, true>(a, stream);
 }
 
@@ -626,6 +712,7 @@ extern "C" int llx_int8_mm_dequant_ext(const void* A, int64_t lda, const void* B
   a.col0 = 0; a.col_end = (int)N;
   a.rope = rope_table; a.rope_S = (int)rope_S; a.rope_cols = (int)rope_cols;
   a.m_valid = nullptr;
+  a.C32 = nullptr; a.splits = 1;
   switch (epilogue) {
     case EPI_RESIDUAL: return launch_gemm<EPI_RESIDUAL, true>(a, stream);
     case EPI_ROPE: return launch_gemm<EPI_ROPE, true>(a, stream);

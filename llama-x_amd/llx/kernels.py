@@ -180,6 +180,33 @@ def gemm_nt(a: Tensor, b: Tensor, *, out: Optional[Tensor] = None, a2: Optional[
     return out
 
 
+def gemm_nt_splitk(a: Tensor, b: Tensor, splits: int, *, m_valid: Optional[Tensor] = None, inv: Optional[Tensor] = None,
+                   dev_scalar: Optional[Tensor] = None, m_expect: Optional[float] = None) -> Tensor:
+    """bf16(dev_scalar * bf16(a[M,K] @ b[N,K]^T)) with the contraction cut in `splits` ranges computed side by side (one launch, fp32
+    partial products, summed by a second small kernel) - for products with few output tiles and a long K.  m_valid: only the first
+    m_valid rows of a exist (device int32); inv: out row i = product row inv[i], zero where inv[i] < 0 (the scatter of compacted rows)."""
+    _chk_bf16(a, b)
+    assert a.dim() == 2 and b.dim() == 2 and a.shape[1] == b.shape[1] and a.stride(1) == 1 and b.stride(1) == 1
+    M, K = a.shape
+    N = b.shape[0]
+    part = torch.empty(splits, M, N, device=a.device, dtype=torch.float32)
+    ev = None
+    if GEMM_TRACE is not None:
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
+    L.check(_lib().llx_gemm_nt_bf16_splitk(L.ptr(a), a.stride(0), L.ptr(b), b.stride(0), L.ptr(part), M, N, K, splits, L.ptr(m_valid), L.stream()),
+            "llx_gemm_nt_bf16_splitk")
+    if ev is not None:
+        ev[1].record()
+        Mw = M if m_expect is None else float(m_expect)
+        GEMM_TRACE.append((ev[0], ev[1], 2.0 * Mw * N * K, 2.0 * (Mw * K + N * K) + 4.0 * splits * Mw * N, "bf16", 1))
+    out = torch.empty(M, N, device=a.device, dtype=BF16)
+    assert inv is None or (inv.dtype is torch.int32 and inv.numel() == M)
+    assert dev_scalar is None or (dev_scalar.dtype is torch.float32 and dev_scalar.numel() == 1)
+    L.check(_lib().llx_splitk_combine(L.ptr(part), splits, M, N, L.ptr(inv), L.ptr(dev_scalar), L.ptr(out), N, L.stream()), "llx_splitk_combine")
+    return out
+
+
 def transpose(x: Tensor, pad_to: int = 1) -> Tensor:
     """[R,C] -> [C,Rp] bf16 copy (Rp = R rounded up to ``pad_to``, zero filled); int8 sources are widened to bf16."""
     L.require_cuda(x)

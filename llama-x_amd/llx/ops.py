@@ -691,6 +691,10 @@ _FUSE_SWIGLU_FWD = os.environ.get("LLX_FUSE_SWIGLU_FWD", "1") != "0"  # A/B knob
 _BATCH_TN_REDUCE = os.environ.get("LLX_BATCH_TN_REDUCE", "1") != "0"  # A/B knob: 0 = every adapter-gradient product reduces its partials at once
 _FUSE_NORM_SKINNY = os.environ.get("LLX_FUSE_NORM_SKINNY", "1") != "0"  # A/B knob: 0 = RMSNorm, then the stand-alone skinny product
 _HEAD_COMPACT = os.environ.get("LLX_HEAD_COMPACT", "1") != "0"  # LM head + loss over the labelled rows only (HeadLossFn)
+# K ranges of the head's d-hidden GEMM (1 = unsplit).  The row count is only known on the device, so the split is static: with 4 ranges
+# a round of 256 tiles lasts a quarter of the unsplit tile time, i.e. the time follows the labelled-row count in steps of 1/4 round
+# (3071 rows: 12 x 16 x 4 = 768 tiles = 3 full rounds; measured -0.5 ms against one long round, 2 ranges = 1.5 rounds gain nothing)
+_HEAD_SPLITK = max(1, int(os.environ.get("LLX_HEAD_SPLITK", "4")))
 _FUSE_NORM_QUANT = os.environ.get("LLX_FUSE_NORM_QUANT", "1") != "0"  # A/B knob: 0 = stand-alone activation quantiser after the RMSNorm
 _FUSE_ROPE = os.environ.get("LLX_FUSE_ROPE", "1") != "0"  # A/B knob: 0 = stand-alone rope kernel after the projection / before its dgrad
 
@@ -782,8 +786,10 @@ class HeadLossFn(Function):
         xn, rstd = K.rmsnorm_fwd(x2, norm_w.detach(), eps)
         need_grad = any(ctx.needs_input_grad)
         ctx.plan, ctx.eps = plan, eps
-        ctx.compact = (_HEAD_COMPACT and not plan.int8 and plan.rank == 0 and plan.bias is None and plan.dora_m is None
-                       and not any(ctx.needs_input_grad[5:]))
+        # a frozen plain head (no adapter, no bias, bf16): only d hidden is wanted from its backward
+        ctx.plain_head = not plan.int8 and plan.rank == 0 and plan.bias is None and plan.dora_m is None and not any(ctx.needs_input_grad[5:])
+        ctx.compact = _HEAD_COMPACT and ctx.plain_head
+        ctx.m_expect = None
         if ctx.compact:
             idx, inv, labels_c, cnt = K.head_compact_index(labels)
             xc = K.gather_rows(xn, idx, cnt)
@@ -805,12 +811,21 @@ class HeadLossFn(Function):
         x, norm_w, x2, xn, rstd, dlogits, t = _load(ctx)
         needs = ctx.needs_input_grad[5:]
         g32 = gout.detach().to(torch.float32).reshape(1)
-        if ctx.compact:
-            inv, cnt = t
+        if ctx.plain_head:
+            # d hidden = d logits . W: [T, D] is ONE round of 256 tiles whatever the row count, with a contraction over the whole
+            # vocabulary - cut in K ranges computed side by side, so that fewer rows (12 x 16 tiles at 3071 labelled rows) still fill
+            # the chip with full rounds of short tiles.  The compacted and the uncompacted path use the same split, so they stay
+            # bit-identical to each other.
+            inv, cnt = t if ctx.compact else (None, None)
             dx = dnw = None
             if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
-                dxc = K.gemm_nt(dlogits, weight_t(plan.weight), m_valid=cnt, m_expect=ctx.m_expect)
-                dxn = K.scatter_rows(dxc, inv, g32)  # d loss scales the rows on their way back to their positions
+                wt = weight_t(plan.weight)
+                if wt.shape[1] % (64 * _HEAD_SPLITK) == 0:
+                    dxn = K.gemm_nt_splitk(dlogits, wt, _HEAD_SPLITK, m_valid=cnt, inv=inv, dev_scalar=g32, m_expect=ctx.m_expect)
+                elif ctx.compact:
+                    dxn = K.scatter_rows(K.gemm_nt(dlogits, wt, m_valid=cnt, m_expect=ctx.m_expect), inv, g32)
+                else:
+                    dxn = K.scale(K.gemm_nt(dlogits, wt), dev_scalar=g32)
                 dx, dnw = K.rmsnorm_bwd(dxn, x2, norm_w.detach(), rstd, ctx.needs_input_grad[1], dw_out=_grad_dst([norm_w]))
             return (dx.view(x.shape) if dx is not None else None, dnw, None, None, None, *([None] * len(needs)))
         dxn, grads = plan.backward(dlogits, xn, t, needs, need_dx=ctx.needs_input_grad[0] or ctx.needs_input_grad[1])

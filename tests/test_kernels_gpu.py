@@ -883,3 +883,33 @@ def test_head_row_compaction_kernels(K, cuda, pattern):
     dx = K.scatter_rows(dxc, inv, gscale)
     assert torch.equal(dx.cpu(), K.scale(dx_full, dev_scalar=gscale).cpu())
     assert not dx.cpu()[labels == -100].any()
+
+
+@pytest.mark.parametrize("M,N,Kd,splits,rows", [(1000, 512, 4096, 2, None), (512, 256, 1024, 4, None), (1000, 512, 4096, 2, 300), (768, 384, 8192, 2, 512)])
+def test_gemm_splitk(K, cuda, M, N, Kd, splits, rows):
+    """llx_gemm_nt_bf16_splitk + llx_splitk_combine: the contraction in `splits` ranges side by side (fp32 partials) against the
+    unsplit kernel (same products, the fp32 sum merely grouped per range: equal up to one bf16 ulp in rare elements) and against a
+    float64 product; with a device row count only the row tiles that hold wanted rows are computed; inv scatters, scale folds in."""
+    g = torch.Generator().manual_seed(11)
+    a = (torch.randn(M, Kd, generator=g) * 0.5).bfloat16().to(cuda)
+    b = (torch.randn(N, Kd, generator=g) * 0.05).bfloat16().to(cuda)
+    ref = (a.double() @ b.double().T).cpu()
+    plain = K.gemm_nt(a, b).float().cpu()
+    cnt = torch.tensor([rows], device=cuda, dtype=torch.int32) if rows is not None else None
+    out = K.gemm_nt_splitk(a, b, splits, m_valid=cnt).float().cpu()
+    n = M if rows is None else rows
+    ulp = torch.exp2(torch.floor(torch.log2(ref[:n].abs().clamp_min(1e-3))) - 7)  # bf16 spacing at the reference value
+    assert ((out[:n] - ref[:n]).abs() <= 0.5 * ulp + 2e-7 * Kd).all()  # correctly rounded up to the fp32 summation noise of Kd terms
+    assert ((out[:n] - plain[:n]).abs() <= ulp).all() and (out[:n] == plain[:n]).float().mean() > 0.995
+    # scatter + scale in the combine: row i of the result = scale * row inv[i] of the product, zero where inv[i] < 0
+    inv = torch.full((M,), -1, dtype=torch.int32)
+    perm = torch.randperm(n, generator=g)[: n // 2]
+    inv[torch.arange(0, 2 * perm.numel(), 2)[: perm.numel()]] = perm.int()
+    sc = torch.tensor([0.25], device=cuda)
+    got = K.gemm_nt_splitk(a, b, splits, m_valid=cnt, inv=inv.to(cuda), dev_scalar=sc).float().cpu()
+    want = torch.zeros(M, N)
+    sel = inv >= 0
+    want[sel] = (out[inv[sel].long()].bfloat16().float() * 0.25).bfloat16().float()
+    assert torch.equal(got, want)
+    with pytest.raises(Exception, match="multiple of 64"):
+        K.gemm_nt_splitk(a[:, : Kd - 64].contiguous(), b[:, : Kd - 64].contiguous(), splits)
