@@ -186,6 +186,9 @@ int llx_skinny_tn(const void* U, const void* Y, int64_t ldy, void* out, int64_t 
  * adapter gradients of one transformer block) in ONE launch; host arrays of length n, entry i = the arguments of product i */
 int llx_skinny_tn_partial(const void* U, const void* Y, int64_t ldy, int64_t M, int64_t N, int64_t R, void* workspace, const int32_t* segs,
                           int seg_count, llx_stream_t s);
+/* first stage of up to 4 products in ONE launch (the d lora_b and d lora_a products of a linear group: different operands, ready together) */
+int llx_skinny_tn_partial_many(int n, const void* const* U, const void* const* Y, const int64_t* ldy, const int64_t* M, const int64_t* N,
+                               const int64_t* R, void* const* workspaces, const int32_t* const* segs, const int* seg_count, llx_stream_t s);
 int llx_skinny_tn_reduce_many(int n, const void* const* workspaces, void* const* outs, const int64_t* out_ld, const int64_t* M, const int64_t* N,
                               const int64_t* R, const float* scale, const int* transpose_out, const int* accumulate,
                               const int32_t* const* segs, const int* seg_count, llx_stream_t s);

@@ -149,14 +149,13 @@ __device__ __forceinline__ bf16x8_t tr16_frag(const char* tile, int rowbytes, in
 // [n_hi - n_lo, r_hi - r_lo] matrix at out + off (offsets in member order), so no slicing copy follows.
 struct TnSegs { int n_lo[4], n_hi[4], r_lo[4], r_hi[4]; int64_t off[4]; int count; int rb_lo[4], rb_hi[4]; };
 
+// One block of the first stage: column tile `ctile` (256 columns of Y), row range `split`.  NB = 16-row blocks of U^T the registers
+// are sized for; nbl <= NB = the product's own count (layout of its partial array: [split][nbl*16][N]).
 template <int NB>
-__global__ __launch_bounds__(256) void skinny_tn_kernel(const bf16_t* __restrict__ U, const bf16_t* __restrict__ Y, int64_t ldy,
-                                                        float* __restrict__ partial, int M, int N, int rows_per_split, TnSegs sg) {
-  __shared__ __attribute__((aligned(16))) char sY[TN_MS * TN_YROW];
-  __shared__ __attribute__((aligned(16))) char sU[TN_MS * TN_UROW];
+__device__ __forceinline__ void skinny_tn_block(const bf16_t* __restrict__ U, const bf16_t* __restrict__ Y, int64_t ldy, float* __restrict__ partial,
+                                                int M, int N, int rows_per_split, const TnSegs& sg, int ctile, int split, int nbl, char* sY, char* sU) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int n0 = blockIdx.x * TN_NT;
-  const int split = blockIdx.y;
+  const int n0 = ctile * TN_NT;
   const int m_begin = split * rows_per_split, m_end = min(M, m_begin + rows_per_split);
   f32x4_t acc[NB][4];
 #pragma unroll
@@ -164,30 +163,30 @@ __global__ __launch_bounds__(256) void skinny_tn_kernel(const bf16_t* __restrict
 #pragma unroll
     for (int cb = 0; cb < 4; ++cb) acc[rb][cb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  // global -> registers (zero rows past the end / columns past N); the loads of step i+1 are issued right after step i's
-  // registers have been written to LDS, so they fly under step i's transposed reads and MFMAs
-  u32x4_t yv[4], uv;
-  auto load_step = [&](int ms) {
+  // global -> registers (zero rows past the end / columns past N), TWO steps ahead: two register sets alternate, the set of step i
+  // is refilled with step i+2 as soon as it has been written to LDS, so two steps of loads (2 x 20 KB per block) fly under the
+  // transposed reads and MFMAs of the current one - one step in flight left the kernel latency-bound at ~3.5 TB/s
+  u32x4_t yv[2][4], uv[2];
+  auto load_step = [&](int set, int ms) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int q = i * 256 + tid;  // chunk of 16 B: row q>>5, chunk q&31
       const int row = ms + (q >> 5), col = n0 + (q & 31) * 8;
-      yv[i] = (row < m_end && col < N) ? *reinterpret_cast<const u32x4_t*>(Y + (int64_t)row * ldy + col) : u32x4_t{0u, 0u, 0u, 0u};
+      yv[set][i] = (row < m_end && col < N) ? *reinterpret_cast<const u32x4_t*>(Y + (int64_t)row * ldy + col) : u32x4_t{0u, 0u, 0u, 0u};
     }
     const int row = ms + (tid >> 3);
-    uv = (row < m_end) ? *reinterpret_cast<const u32x4_t*>(U + (int64_t)row * SK_PAD + (tid & 7) * 8) : u32x4_t{0u, 0u, 0u, 0u};
+    uv[set] = (row < m_end) ? *reinterpret_cast<const u32x4_t*>(U + (int64_t)row * SK_PAD + (tid & 7) * 8) : u32x4_t{0u, 0u, 0u, 0u};
   };
-  if (m_begin < m_end) load_step(m_begin);
-  for (int ms = m_begin; ms < m_end; ms += TN_MS) {
+  auto step = [&](int set, int ms) {
     __syncthreads();  // previous step's reads are done
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int q = i * 256 + tid;
-      *reinterpret_cast<u32x4_t*>(sY + (q >> 5) * TN_YROW + (q & 31) * 16) = yv[i];
+      *reinterpret_cast<u32x4_t*>(sY + (q >> 5) * TN_YROW + (q & 31) * 16) = yv[set][i];
     }
-    *reinterpret_cast<u32x4_t*>(sU + (tid >> 3) * TN_UROW + (tid & 7) * 16) = uv;
+    *reinterpret_cast<u32x4_t*>(sU + (tid >> 3) * TN_UROW + (tid & 7) * 16) = uv[set];
     __syncthreads();
-    if (ms + TN_MS < m_end) load_step(ms + TN_MS);
+    if (ms + 2 * TN_MS < m_end) load_step(set, ms + 2 * TN_MS);
     bf16x8_t a[NB];
 #pragma unroll
     for (int rb = 0; rb < NB; ++rb) a[rb] = tr16_frag(sU, TN_UROW, rb * 16, lane);
@@ -198,6 +197,12 @@ __global__ __launch_bounds__(256) void skinny_tn_kernel(const bf16_t* __restrict
       for (int rb = 0; rb < NB; ++rb)
         if (n0 + TN_NT > sg.rb_lo[rb] && n0 < sg.rb_hi[rb]) acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[rb], b, acc[rb][cb], 0, 0, 0);
     }
+  };
+  if (m_begin < m_end) load_step(0, m_begin);
+  if (m_begin + TN_MS < m_end) load_step(1, m_begin + TN_MS);
+  for (int ms = m_begin; ms < m_end; ms += 2 * TN_MS) {
+    step(0, ms);
+    if (ms + TN_MS < m_end) step(1, ms + TN_MS);
   }
   // D[row = r][col = n]: lane -> n = lane&15, r = (lane>>4)*4 + e
   const int fr = lane & 15, fq = lane >> 4;
@@ -208,9 +213,33 @@ __global__ __launch_bounds__(256) void skinny_tn_kernel(const bf16_t* __restrict
       const int n = n0 + wave * 64 + cb * 16 + fr;
       if (n < N && n0 + TN_NT > sg.rb_lo[rb] && n0 < sg.rb_hi[rb]) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) partial[((int64_t)split * (NB * 16) + rb * 16 + fq * 4 + e) * N + n] = acc[rb][cb][e];
+        for (int e = 0; e < 4; ++e) partial[((int64_t)split * (nbl * 16) + rb * 16 + fq * 4 + e) * N + n] = acc[rb][cb][e];
       }
     }
+}
+
+template <int NB>
+__global__ __launch_bounds__(256) void skinny_tn_kernel(const bf16_t* __restrict__ U, const bf16_t* __restrict__ Y, int64_t ldy,
+                                                        float* __restrict__ partial, int M, int N, int rows_per_split, TnSegs sg) {
+  __shared__ __attribute__((aligned(16))) char sY[TN_MS * TN_YROW];
+  __shared__ __attribute__((aligned(16))) char sU[TN_MS * TN_UROW];
+  skinny_tn_block<NB>(U, Y, ldy, partial, M, N, rows_per_split, sg, blockIdx.x, blockIdx.y, NB, sY, sU);
+}
+
+// First stage of up to TN_MANY products in ONE launch (the dB and dA products of a linear group read different operands but are ready
+// together: one ramp-up and one tail instead of two, and the small product's blocks fill the gaps of the big one).  blockIdx.x walks
+// the products' blocks back to back; row blocks past a product's own count are switched off through its rb_lo / rb_hi table.
+#define TN_MANY 4
+struct TnPart { const bf16_t* U; const bf16_t* Y; int64_t ldy; float* partial; int M, N, rows_per_split, ctiles, nblocks, nbl; TnSegs sg; };
+struct TnPartMany { TnPart d[TN_MANY]; int n; };
+
+__global__ __launch_bounds__(256) void skinny_tn_many_kernel(const TnPartMany m) {
+  __shared__ __attribute__((aligned(16))) char sY[TN_MS * TN_YROW];
+  __shared__ __attribute__((aligned(16))) char sU[TN_MS * TN_UROW];
+  int b = blockIdx.x, i = 0;
+  while (i < m.n - 1 && b >= m.d[i].nblocks) { b -= m.d[i].nblocks; ++i; }
+  const TnPart& d = m.d[i];
+  skinny_tn_block<4>(d.U, d.Y, d.ldy, d.partial, d.M, d.N, d.rows_per_split, d.sg, b % d.ctiles, b / d.ctiles, d.nbl, sY, sU);
 }
 
 // (second stage: skinny_tn_reduce_many_kernel below - out = bf16(scale * sum_split partial[split][r][n] (+ out)), plain [R,N] / [N,R] or member segments)
@@ -276,8 +305,38 @@ extern "C" int llx_skinny_tn_partial(const void* U, const void* Y, int64_t ldy, 
   return LLX_OK;
 }
 
+// Arrays of length n (<= 4), one entry per product, arguments as llx_skinny_tn_partial.
+extern "C" int llx_skinny_tn_partial_many(int n, const void* const* U, const void* const* Y, const int64_t* ldy, const int64_t* M, const int64_t* N,
+                                          const int64_t* R, void* const* workspaces, const int32_t* const* segs, const int* seg_count,
+                                          hipStream_t stream) {
+  LLX_REQUIRE(n >= 1 && n <= TN_MANY && U && Y && ldy && M && N && R && workspaces && segs && seg_count, "llx_skinny_tn_partial_many: bad arguments (1..4 products)");
+  TnPartMany m;
+  m.n = n;
+  int total_blocks = 0;
+  for (int i = 0; i < n; ++i) {
+    TnPart& d = m.d[i];
+    LLX_REQUIRE(U[i] && Y[i] && workspaces[i], "llx_skinny_tn_partial_many: null pointer (product %d)", i);
+    LLX_REQUIRE(M[i] > 0 && N[i] > 0 && N[i] % 8 == 0 && R[i] > 0 && R[i] <= 64 && ldy[i] % 8 == 0, "llx_skinny_tn_partial_many: need N%%8==0, ldy%%8==0, 0<R<=64 (product %d)", i);
+    LLX_REQUIRE(((uintptr_t)U[i] | (uintptr_t)Y[i]) % 16 == 0, "llx_skinny_tn_partial_many: unaligned pointer (product %d)", i);
+    const int nsplit = tn_splits(M[i], N[i]);
+    d.U = (const bf16_t*)U[i]; d.Y = (const bf16_t*)Y[i]; d.ldy = ldy[i]; d.partial = (float*)workspaces[i];
+    d.M = (int)M[i]; d.N = (int)N[i];
+    d.rows_per_split = (int)cdiv64(cdiv64(M[i], nsplit), TN_MS) * TN_MS;
+    d.ctiles = (int)cdiv64(N[i], TN_NT);
+    d.nblocks = d.ctiles * nsplit;
+    d.nbl = (int)cdiv64(R[i], 16);
+    int64_t total = 0;
+    const int rc = tn_fill_segs(d.sg, segs[i], seg_count[i], N[i], R[i], &total);
+    if (rc != LLX_OK) return rc;
+    for (int rb = d.nbl; rb < 4; ++rb) { d.sg.rb_lo[rb] = d.N; d.sg.rb_hi[rb] = 0; }  // row blocks this product does not have
+    total_blocks += d.nblocks;
+  }
+  hipLaunchKernelGGL(skinny_tn_many_kernel, dim3((unsigned)total_blocks), dim3(256), 0, stream, m);
+  LLX_LAUNCH_CHECK("llx_skinny_tn_partial_many");
+  return LLX_OK;
+}
+
 // second stage of up to TN_MANY products in ONE launch (the four adapter gradients of a transformer block): blockIdx.y picks the product.
-#define TN_MANY 4
 struct TnRed { const float* partial; bf16_t* out; int64_t out_ld, total; int nsplit, RP, R, N, transpose_out, accumulate, use_segs; float scale; TnSegs sg; };
 struct TnRedMany { TnRed d[TN_MANY]; };
 

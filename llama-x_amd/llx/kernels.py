@@ -677,12 +677,14 @@ def skinny_nt(x: Tensor, w: Tensor, kranges: Optional[Sequence[int]] = None) -> 
 
 
 def skinny_tn(u: Tensor, y: Tensor, R: int, scale_: float, out: Tensor, transpose_out: bool, accumulate: bool = False,
-              segs: Optional[Sequence[tuple[int, int, int, int]]] = None, pending: Optional[list] = None) -> Tensor:
+              segs: Optional[Sequence[tuple[int, int, int, int]]] = None, pending: Optional[list] = None, defer: bool = False) -> Tensor:
     """out ([R,N], or [N,R] when transpose_out) (+)= scale * u[:, :R]^T @ y, u [M,64], y [M,N].
     segs: members (n_lo, n_hi, r_lo, r_hi) of a fused group (block-diagonal product): out is then a flat buffer that receives the
     members' [n, r] blocks one after another, each contiguous.
     pending: a list - only the first stage (fp32 split partials) is launched and the second stage is appended to it; ``out`` is valid
-    once skinny_tn_flush(pending) has run (one launch for up to 4 products: the adapter gradients of a transformer block)."""
+    once skinny_tn_flush(pending) has run (one launch for up to 4 products: the adapter gradients of a transformer block).
+    defer (with pending): the first stage waits too, until skinny_tn_partials(pending) / the flush launches it together with the other
+    queued products (u and y must stay untouched until then)."""
     _chk_bf16(u, y, out)
     M, N = y.shape
     assert u.shape == (M, SK_PAD) and u.is_contiguous() and y.stride(1) == 1 and out.stride(-1) == 1
@@ -699,15 +701,45 @@ def skinny_tn(u: Tensor, y: Tensor, R: int, scale_: float, out: Tensor, transpos
         L.check(_lib().llx_skinny_tn(L.ptr(u), L.ptr(y), y.stride(0), L.ptr(out), out_ld, M, N, R, scale_, int(transpose_out), int(accumulate),
                                      L.ptr(ws), sp, ns, L.stream()), "llx_skinny_tn")
         return out
-    L.check(_lib().llx_skinny_tn_partial(L.ptr(u), L.ptr(y), y.stride(0), M, N, R, L.ptr(ws), sp, ns, L.stream()), "llx_skinny_tn_partial")
-    pending.append((ws, out, out_ld, M, N, R, scale_, int(transpose_out), int(accumulate), sp, ns))
+    # queued: [ws, out, out_ld, M, N, R, scale, transpose_out, accumulate, segs, n_segs, first stage not launched yet?, u, y]
+    pending.append([ws, out, out_ld, M, N, R, scale_, int(transpose_out), int(accumulate), sp, ns, True, u, y])
+    if not defer:
+        skinny_tn_partials(pending)
     if len(pending) == 4:
         skinny_tn_flush(pending)
     return out
 
 
+def skinny_tn_partials(pending: list) -> None:
+    """First stage (fp32 split partials) of every queued product that has not had it yet, in ONE launch (up to 4 products): the dB and
+    dA products of a linear group are queued with defer=True and launched together."""
+    todo = [c for c in pending if c[11]]
+    while todo:
+        chunk, todo = todo[:4], todo[4:]
+        n = len(chunk)
+        if n == 1:
+            c = chunk[0]
+            L.check(_lib().llx_skinny_tn_partial(L.ptr(c[12]), L.ptr(c[13]), c[13].stride(0), c[3], c[4], c[5], L.ptr(c[0]), c[9], c[10], L.stream()),
+                    "llx_skinny_tn_partial")
+        else:
+            UU = (ctypes.c_void_p * n)(*[c[12].data_ptr() for c in chunk])
+            YY = (ctypes.c_void_p * n)(*[c[13].data_ptr() for c in chunk])
+            LY = (ctypes.c_int64 * n)(*[c[13].stride(0) for c in chunk])
+            MM = (ctypes.c_int64 * n)(*[c[3] for c in chunk])
+            NN = (ctypes.c_int64 * n)(*[c[4] for c in chunk])
+            RR = (ctypes.c_int64 * n)(*[c[5] for c in chunk])
+            WS = (ctypes.c_void_p * n)(*[c[0].data_ptr() for c in chunk])
+            SG = (ctypes.c_void_p * n)(*[ctypes.cast(c[9], ctypes.c_void_p).value if c[9] is not None else None for c in chunk])
+            NS = (ctypes.c_int * n)(*[c[10] for c in chunk])
+            L.check(_lib().llx_skinny_tn_partial_many(n, UU, YY, LY, MM, NN, RR, WS, SG, NS, L.stream()), "llx_skinny_tn_partial_many")
+        for c in chunk:
+            c[11] = False
+            c[12] = c[13] = None  # the operands are not needed past the first stage
+
+
 def skinny_tn_flush(pending: list) -> None:
     """Second stage of every product queued by skinny_tn(..., pending=...) in one launch (at most 4 per launch)."""
+    skinny_tn_partials(pending)
     while pending:
         chunk, pending[:] = pending[:4], pending[4:]
         n = len(chunk)

@@ -423,7 +423,7 @@ class GroupPlan:
                 flat = _grad_dst([m.lora_b for m in self.members if m.rank > 0])  # the arena keeps a group's B factors back to back
                 if flat is None:
                     flat = torch.empty(sum((b - a) * (d - c_) for a, b, c_, d in segs), device=dy.device, dtype=BF16)
-                K.skinny_tn(t, dy, self.R, self.scale, flat, transpose_out=True, segs=segs, pending=pending)
+                K.skinny_tn(t, dy, self.R, self.scale, flat, transpose_out=True, segs=segs, pending=pending, defer=need_a and _BATCH_TN_PARTIAL)
                 gB_views, off = [], 0
                 for m_, (a, b, c_, d) in zip([m for m in self.members if m.rank > 0], segs):
                     gB_views.append(flat[off : off + (b - a) * (d - c_)].view(b - a, d - c_))
@@ -437,7 +437,7 @@ class GroupPlan:
                 gA = _grad_dst([m.lora_a for m in self.members if m.rank > 0], (self.R, self.K))  # ... and its A factors
                 if gA is None:
                     gA = torch.empty(self.R, self.K, device=dy.device, dtype=BF16)
-                K.skinny_tn(u, x, self.R, self.scale, gA, transpose_out=False, pending=pending)
+                K.skinny_tn(u, x, self.R, self.scale, gA, transpose_out=False, pending=pending)  # launches the deferred dB stage with its own
         dx = None
         if need_dx:
             g = K.scale(dy, colscale=self.scale_cat()) if self.int8 else dy  # (g * scale) rounded (subclasses/int8.py:127)
@@ -690,6 +690,7 @@ class AttnBlockFn(Function):
 _FUSE_SWIGLU_FWD = os.environ.get("LLX_FUSE_SWIGLU_FWD", "1") != "0"  # A/B knob: 0 = stand-alone swiglu_fwd kernel
 _BATCH_TN_REDUCE = os.environ.get("LLX_BATCH_TN_REDUCE", "1") != "0"  # A/B knob: 0 = every adapter-gradient product reduces its partials at once
 _FUSE_NORM_SKINNY = os.environ.get("LLX_FUSE_NORM_SKINNY", "1") != "0"  # A/B knob: 0 = RMSNorm, then the stand-alone skinny product
+_BATCH_TN_PARTIAL = os.environ.get("LLX_BATCH_TN_PARTIAL", "1") != "0"  # A/B knob: 0 = dB's first stage launched on its own, before u
 _HEAD_COMPACT = os.environ.get("LLX_HEAD_COMPACT", "1") != "0"  # LM head + loss over the labelled rows only (HeadLossFn)
 # K ranges of the head's d-hidden GEMM (1 = unsplit).  The row count is only known on the device, so the split is static: with 4 ranges
 # a round of 256 tiles lasts a quarter of the unsplit tile time, i.e. the time follows the labelled-row count in steps of 1/4 round

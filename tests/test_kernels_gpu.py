@@ -913,3 +913,39 @@ def test_gemm_splitk(K, cuda, M, N, Kd, splits, rows):
     assert torch.equal(got, want)
     with pytest.raises(Exception, match="multiple of 64"):
         K.gemm_nt_splitk(a[:, : Kd - 64].contiguous(), b[:, : Kd - 64].contiguous(), splits)
+
+
+def test_skinny_tn_batched_stages(K, cuda):
+    """Products queued with pending / defer: the first stages of several products run as ONE launch (llx_skinny_tn_partial_many, products
+    with 1, 2, 3 row blocks and a segmented one side by side), the second stages as one more - bit-identical to the stand-alone calls."""
+    M = 1000
+    specs = [(768, 16, False, None), (1280, 32, True, None), (512, 48, False, None), (1024, 24, True, [(0, 512, 0, 8), (512, 1024, 8, 24)])]
+    args, want = [], []
+    for i, (N, R, tr, segs) in enumerate(specs):
+        u = torch.zeros(M, 64, dtype=torch.bfloat16)
+        u[:, :R] = _bf(O.randn(f"u{i}", (M, R)))
+        y = _bf(O.randn(f"y{i}", (M, N)))
+        shape = (sum((b - a) * (d - c) for a, b, c, d in segs),) if segs else ((N, R) if tr else (R, N))
+        ref = torch.empty(*shape, device=cuda, dtype=torch.bfloat16)
+        K.skinny_tn(u.to(cuda), y.to(cuda), R, 0.25, ref, tr, segs=segs)
+        args.append((u.to(cuda), y.to(cuda), R, tr, segs, shape))
+        want.append(ref)
+    for defer in (True, False):
+        pend, outs = [], []
+        for u, y, R, tr, segs, shape in args:
+            out = torch.full(shape, float("nan"), device=cuda, dtype=torch.bfloat16)
+            K.skinny_tn(u, y, R, 0.25, out, tr, segs=segs, pending=pend, defer=defer)
+            outs.append(out)
+        assert not pend  # the fourth product triggers the flush (first stages together when deferred, then the second stages)
+        for o, w in zip(outs, want):
+            assert torch.equal(o, w)
+    # two deferred products, launched explicitly, flushed later
+    pend = []
+    outs = [torch.empty(s[5], device=cuda, dtype=torch.bfloat16) for s in args[:2]]
+    for (u, y, R, tr, segs, _), out in zip(args[:2], outs):
+        K.skinny_tn(u, y, R, 0.25, out, tr, segs=segs, pending=pend, defer=True)
+    assert all(c[11] for c in pend)
+    K.skinny_tn_partials(pend)
+    assert not any(c[11] for c in pend) and len(pend) == 2
+    K.skinny_tn_flush(pend)
+    assert torch.equal(outs[0], want[0]) and torch.equal(outs[1], want[1])
