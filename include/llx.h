@@ -173,6 +173,10 @@ int llx_ce_fwd_bwd_rows(const void* logits, int64_t ld, void* dlogits, int64_t d
  *      G = s * U^T.Y with fp32 split partials (deterministic). --------------------------------------------------- */
 int llx_skinny_nt(const void* X, int64_t ldx, const void* W, int64_t ldw, void* out, int64_t M, int64_t K, int64_t R,
                   const int32_t* kranges /* host, nullable: {lo,hi} x 4 per 16 rows of a block-diagonal W */, llx_stream_t s);
+/* llx_skinny_nt that also writes G[M,K] = bf16(X * colscale[k]) (row stride ldg) from the same read of X: the (grad_output * scale)
+ * operand of a weight-only int8 linear's data gradient (subclasses/int8.py:127) rides in the adapter's dy @ lora_b pass. */
+int llx_skinny_nt_scaled(const void* X, int64_t ldx, const void* W, int64_t ldw, void* out, int64_t M, int64_t K, int64_t R,
+                         const int32_t* kranges, const void* colscale, void* G, int64_t ldg, llx_stream_t s);
 /* nn.RMSNorm (modelling/llama.py:158-160) and the adapter's x @ lora_a^T on its output (modelling/lora.py:43) from ONE read of x:
  * y = rmsnorm(x) [M,D], rstd fp32 [M], t = y . W^T [M,64 padded] (W = the group's stacked lora_a [R,D]).  D % 512 == 0, D <= 4096. */
 int llx_rmsnorm_skinny_nt(const void* x, const void* g, const void* W, int64_t ldw, void* y, float* rstd, void* t, int64_t M, int64_t D,

@@ -20,9 +20,23 @@ typedef __attribute__((ext_vector_type(8))) short s16x8_t;
 // outside a row block's range are skipped - no W fragment load, no MFMA.  Dense W: lo = 0, hi = K.
 struct SkinnyRanges { int lo[4], hi[4]; };
 
-template <int NB, bool RANGED>
+// SCALE: the kernel also writes G[m, k] = bf16(X[m, k] * cs[k]) (row stride ldg) from the fragments it has just loaded - the
+// (grad_output * scale) operand of a weight-only int8 linear's data gradient (subclasses/int8.py:127) rides in the adapter's dy @ B
+// pass instead of costing its own read of dy.
+__device__ __forceinline__ void snt_scaled_store(const bf16x8_t& a, const bf16_t* cs, bf16_t* g) {
+  const u32x4_t x = __builtin_bit_cast(u32x4_t, a);
+  const u32x4_t c = *reinterpret_cast<const u32x4_t*>(cs);
+  u32x4_t o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) o[e] = pack_bf2(bflo(x[e]) * bflo(c[e]), bfhi(x[e]) * bfhi(c[e]));
+  *reinterpret_cast<u32x4_t*>(g) = o;  // (a non-temporal store here was measured slower: +0.5 ms on the int8 step)
+}
+
+template <int NB, bool RANGED, bool SCALE = false>
 __global__ __launch_bounds__(SNT_WAVES * 64) void skinny_nt_kernel(const bf16_t* __restrict__ X, int64_t ldx, const bf16_t* __restrict__ W,
-                                                                   int64_t ldw, bf16_t* __restrict__ out, int M, int K, int R, SkinnyRanges kr) {
+                                                                   int64_t ldw, bf16_t* __restrict__ out, int M, int K, int R, SkinnyRanges kr,
+                                                                   const bf16_t* __restrict__ cs = nullptr, bf16_t* __restrict__ G = nullptr,
+                                                                   int64_t ldg = 0) {
   __shared__ float part[SNT_WAVES][16][SK_PAD];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int m0 = blockIdx.x * 16;
@@ -49,6 +63,15 @@ __global__ __launch_bounds__(SNT_WAVES * 64) void skinny_nt_kernel(const bf16_t*
     bf16x8_t a[SNT_UNROLL], b[SNT_UNROLL][NB];
 #pragma unroll
     for (int u = 0; u < SNT_UNROLL; ++u) a[u] = *reinterpret_cast<const bf16x8_t*>(xrow + (pr + (u >> 1) * SNT_WAVES) * 64 + 16 * fq + 8 * (u & 1));
+    if constexpr (SCALE) {
+      if (m0 + fr < M) {
+#pragma unroll
+        for (int u = 0; u < SNT_UNROLL; ++u) {
+          const int k = (pr + (u >> 1) * SNT_WAVES) * 64 + 16 * fq + 8 * (u & 1);
+          snt_scaled_store(a[u], cs + k, G + (int64_t)(m0 + fr) * ldg + k);
+        }
+      }
+    }
 #pragma unroll
     for (int u = 0; u < SNT_UNROLL; ++u) {
       const int k0 = (pr + (u >> 1) * SNT_WAVES) * 64;  // wave-uniform
@@ -70,6 +93,9 @@ __global__ __launch_bounds__(SNT_WAVES * 64) void skinny_nt_kernel(const bf16_t*
     const int pr_done = rounds * (SNT_UNROLL / 2) * SNT_WAVES;  // pairs [0, pr_done) are finished
     for (int ks = 2 * pr_done + wave; ks < nks; ks += SNT_WAVES) {
       const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(xrow + ks * 32 + 8 * fq);
+      if constexpr (SCALE) {
+        if (m0 + fr < M) snt_scaled_store(a, cs + ks * 32 + 8 * fq, G + (int64_t)(m0 + fr) * ldg + ks * 32 + 8 * fq);
+      }
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
         if (RANGED && (ks * 32 < kr.lo[nb] || ks * 32 >= kr.hi[nb])) continue;
@@ -123,6 +149,30 @@ extern "C" int llx_skinny_nt(const void* X, int64_t ldx, const void* W, int64_t 
   else { if (nb == 1) L(1, false); else if (nb == 2) L(2, false); else L(4, false); }
 #undef L
   LLX_LAUNCH_CHECK("llx_skinny_nt");
+  return LLX_OK;
+}
+
+// llx_skinny_nt that also writes G[M, K] = bf16(X * colscale[k]) (row stride ldg) from the same read of X.
+extern "C" int llx_skinny_nt_scaled(const void* X, int64_t ldx, const void* W, int64_t ldw, void* out, int64_t M, int64_t K, int64_t R,
+                                    const int32_t* kranges, const void* colscale, void* G, int64_t ldg, hipStream_t stream) {
+  LLX_REQUIRE(X && W && out && colscale && G, "llx_skinny_nt_scaled: null pointer");
+  LLX_REQUIRE(M > 0 && K > 0 && K % 32 == 0 && R > 0 && R <= 64, "llx_skinny_nt_scaled: need K%%32==0 and 0<R<=64 (K=%lld R=%lld)", (long long)K, (long long)R);
+  LLX_REQUIRE(ldx % 8 == 0 && ldw % 8 == 0 && ldg % 8 == 0 && ((uintptr_t)X | (uintptr_t)W | (uintptr_t)colscale | (uintptr_t)G) % 16 == 0 && (uintptr_t)out % 8 == 0,
+              "llx_skinny_nt_scaled: alignment");
+  const dim3 grid((unsigned)cdiv64(M, 16)), block(SNT_WAVES * 64);
+  const int nb = (int)cdiv64(R, 16);
+  SkinnyRanges kr;
+  for (int i = 0; i < 4; ++i) {
+    kr.lo[i] = kranges ? kranges[2 * i] : 0;
+    kr.hi[i] = kranges ? kranges[2 * i + 1] : (int)K;
+    LLX_REQUIRE(kr.lo[i] % 64 == 0 && (kr.hi[i] % 64 == 0 || kr.hi[i] == (int)K) && kr.lo[i] >= 0 && kr.hi[i] <= (int)K,
+                "llx_skinny_nt_scaled: k range %d of a block-diagonal W must be a multiple of 64 inside [0, K]", i);
+  }
+#define L(N, RG) hipLaunchKernelGGL((skinny_nt_kernel<N, RG, true>), grid, block, 0, stream, (const bf16_t*)X, ldx, (const bf16_t*)W, ldw, (bf16_t*)out, (int)M, (int)K, (int)R, kr, (const bf16_t*)colscale, (bf16_t*)G, ldg)
+  if (kranges) { if (nb == 1) L(1, true); else if (nb == 2) L(2, true); else L(4, true); }
+  else { if (nb == 1) L(1, false); else if (nb == 2) L(2, false); else L(4, false); }
+#undef L
+  LLX_LAUNCH_CHECK("llx_skinny_nt_scaled");
   return LLX_OK;
 }
 

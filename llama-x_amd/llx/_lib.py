@@ -70,6 +70,7 @@ SIGNATURES: dict[str, tuple] = {
     "llx_gather_rows": (c_int, [_P, _L, _P, _P, _P, _L, _L, _L, _P]),
     "llx_scatter_rows": (c_int, [_P, _L, _P, _P, _P, _L, _L, _L, _P]),
     "llx_skinny_nt": (c_int, [_P, _L, _P, _L, _P, _L, _L, _L, _P, _P]),
+    "llx_skinny_nt_scaled": (c_int, [_P, _L, _P, _L, _P, _L, _L, _L, _P, _P, _P, _L, _P]),
     "llx_rmsnorm_skinny_nt": (c_int, [_P, _P, _P, _L, _P, _P, _P, _L, _L, _L, _F, _P]),
     "llx_skinny_tn_workspace_bytes": (c_int64, [_L, _L, _L]),
     "llx_skinny_tn": (c_int, [_P, _P, _L, _P, _L, _L, _L, _L, _F, _I, _I, _P, _P, _I, _P]),

@@ -660,10 +660,11 @@ def ce_fwd_bwd(logits: Tensor, labels: Tensor, write_grad: bool, rows: Optional[
 
 
 # ------------------------------------------------------------------------------------------------- skinny (LoRA)
-def skinny_nt(x: Tensor, w: Tensor, kranges: Optional[Sequence[int]] = None) -> Tensor:
+def skinny_nt(x: Tensor, w: Tensor, kranges: Optional[Sequence[int]] = None, colscale: Optional[Tensor] = None):
     """[M,K] @ [R,K]^T -> [M,64] bf16, zero beyond column R.
-    kranges: (lo, hi) x 4, multiples of 64 - rows 16*nb..16*nb+15 of a block-diagonal w are zero outside k in [lo_nb, hi_nb)."""
-    _chk_bf16(x, w)
+    kranges: (lo, hi) x 4, multiples of 64 - rows 16*nb..16*nb+15 of a block-diagonal w are zero outside k in [lo_nb, hi_nb).
+    colscale [K] bf16: returns (out, g) with g [M,K] = bf16(x * colscale) written from the same read of x."""
+    _chk_bf16(x, w, colscale)
     assert x.dim() == 2 and w.dim() == 2 and x.shape[1] == w.shape[1] and x.stride(1) == 1 and w.stride(1) == 1
     M, K = x.shape
     R = w.shape[0]
@@ -672,6 +673,12 @@ def skinny_nt(x: Tensor, w: Tensor, kranges: Optional[Sequence[int]] = None) -> 
     if kranges is not None:
         assert len(kranges) == 8
         kr = (ctypes.c_int32 * 8)(*[int(v) for v in kranges])
+    if colscale is not None:
+        assert colscale.shape == (K,) and colscale.is_contiguous()
+        g = torch.empty(M, K, device=x.device, dtype=BF16)
+        L.check(_lib().llx_skinny_nt_scaled(L.ptr(x), x.stride(0), L.ptr(w), w.stride(0), L.ptr(out), M, K, R, kr, L.ptr(colscale), L.ptr(g), K,
+                                            L.stream()), "llx_skinny_nt_scaled")
+        return out, g
     L.check(_lib().llx_skinny_nt(L.ptr(x), x.stride(0), L.ptr(w), w.stride(0), L.ptr(out), M, K, R, kr, L.stream()), "llx_skinny_nt")
     return out
 

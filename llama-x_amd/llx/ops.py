@@ -431,8 +431,13 @@ class GroupPlan:
             else:
                 gBt = torch.empty(self.N, self.R, device=dy.device, dtype=BF16)
                 K.skinny_tn(t, dy, self.R, self.scale, gBt, transpose_out=True)  # (sliced below: needs the finished product)
+        g_scaled = None
         if self.R > 0:  # u = dy.B, then dA = s u^T.x
-            u = K.skinny_nt(dy, bT, self._kranges())  # [M,64]: column block i = dy_i @ B_i
+            if self.int8 and need_dx and _FUSE_DY_SCALE:
+                # ... and (dy * scale), the int8 base's data-gradient operand (subclasses/int8.py:127), from the same read of dy
+                u, g_scaled = K.skinny_nt(dy, bT, self._kranges(), colscale=self.scale_cat())
+            else:
+                u = K.skinny_nt(dy, bT, self._kranges())  # [M,64]: column block i = dy_i @ B_i
             if need_a:
                 gA = _grad_dst([m.lora_a for m in self.members if m.rank > 0], (self.R, self.K))  # ... and its A factors
                 if gA is None:
@@ -440,7 +445,10 @@ class GroupPlan:
                 K.skinny_tn(u, x, self.R, self.scale, gA, transpose_out=False, pending=pending)  # launches the deferred dB stage with its own
         dx = None
         if need_dx:
-            g = K.scale(dy, colscale=self.scale_cat()) if self.int8 else dy  # (g * scale) rounded (subclasses/int8.py:127)
+            if self.int8:
+                g = g_scaled if g_scaled is not None else K.scale(dy, colscale=self.scale_cat())  # (g * scale) rounded (subclasses/int8.py:127)
+            else:
+                g = dy
             if swiglu is not None:
                 dx = K.gemm_nt(g, self.wt_cat(), out=swiglu[1], a2=u, b2=a2t if self.R > 0 else None, epilogue=K.EPI_SWIGLU_BWD, e=swiglu[0], k2_eff=self.R)
             else:
@@ -690,6 +698,7 @@ class AttnBlockFn(Function):
 _FUSE_SWIGLU_FWD = os.environ.get("LLX_FUSE_SWIGLU_FWD", "1") != "0"  # A/B knob: 0 = stand-alone swiglu_fwd kernel
 _BATCH_TN_REDUCE = os.environ.get("LLX_BATCH_TN_REDUCE", "1") != "0"  # A/B knob: 0 = every adapter-gradient product reduces its partials at once
 _FUSE_NORM_SKINNY = os.environ.get("LLX_FUSE_NORM_SKINNY", "1") != "0"  # A/B knob: 0 = RMSNorm, then the stand-alone skinny product
+_FUSE_DY_SCALE = os.environ.get("LLX_FUSE_DY_SCALE", "1") != "0"  # A/B knob: 0 = stand-alone dy * scale pass for an int8 base's data gradient
 _BATCH_TN_PARTIAL = os.environ.get("LLX_BATCH_TN_PARTIAL", "1") != "0"  # A/B knob: 0 = dB's first stage launched on its own, before u
 _HEAD_COMPACT = os.environ.get("LLX_HEAD_COMPACT", "1") != "0"  # LM head + loss over the labelled rows only (HeadLossFn)
 # K ranges of the head's d-hidden GEMM (1 = unsplit).  The row count is only known on the device, so the split is static: with 4 ranges

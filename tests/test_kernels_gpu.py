@@ -949,3 +949,22 @@ def test_skinny_tn_batched_stages(K, cuda):
     assert not any(c[11] for c in pend) and len(pend) == 2
     K.skinny_tn_flush(pend)
     assert torch.equal(outs[0], want[0]) and torch.equal(outs[1], want[1])
+
+
+@pytest.mark.parametrize("M,Kd,R,ranged", [(1000, 4096 + 2048, 16, False), (515, 2048 + 96, 48, False), (777, 4096, 32, True)])
+def test_skinny_nt_with_scaled_copy(K, cuda, M, Kd, R, ranged):
+    """llx_skinny_nt_scaled: u = x @ w^T as llx_skinny_nt AND g = bf16(x * colscale) (the int8 backward's grad_output * scale,
+    subclasses/int8.py:127) from the same read of x - both bit-identical to the stand-alone kernels."""
+    x = _bf(O.randn("x", (M, Kd))).to(cuda)
+    w = _bf(O.randn("w", (R, Kd)))
+    kr = None
+    if ranged:  # block-diagonal w: rows 0-15 meet k in [0, 2048), rows 16-31 k in [2048, 4096)
+        w[:16, 2048:] = 0
+        w[16:, :2048] = 0
+        kr = [0, 2048, 2048, 4096, 0, 0, 0, 0]
+    w = w.to(cuda)
+    cs = (_bf(O.randn("cs", (Kd,))).abs() * 0.01 + 0.001).bfloat16().to(cuda)
+    u0 = K.skinny_nt(x, w, kr)
+    u, g = K.skinny_nt(x, w, kr, colscale=cs)
+    assert torch.equal(u, u0)
+    assert torch.equal(g, K.scale(x, colscale=cs))
