@@ -23,6 +23,9 @@ their version counters, which an update through a flat alias would not bump.
 Accumulation micro-steps and anything that does not write in place stay correct: a gradient that finds ``param.grad`` already set is
 produced in a fresh buffer and added by autograd (into the arena view), and ``settle()`` repairs whatever ended up elsewhere (copies a
 foreign ``.grad`` into its slot, zeroes the slot of a parameter that got no gradient) before the exchange / optimizer read G.
+Build the arena LAST - after adapters are applied, the base is quantised, requires_grad flags are final and the model sits on its device
+(``model.to(...)`` re-creates parameter storage and would cut the views; ``load_state_dict`` copies in place and is fine).  ``verify()``
+checks that every trainable parameter is still covered and still aliases the arena.
 The checkpoint wire format keeps the reference's per-parameter optimizer state (train_metamathqa.py:259-265): ``optim_state_dict`` /
 ``load_optim_state_dict`` translate.
 """
@@ -113,6 +116,20 @@ class TrainableArena:
     # ---- what the optimizer is built on
     def params(self) -> list[nn.Parameter]:
         return self.flat + self.dense
+
+    def verify(self, model: nn.Module) -> None:
+        """Raises if the model's trainable parameters are no longer exactly the arena's (an adapter added, a flag flipped, the model moved
+        to another device after the arena was built): the flat optimizer would silently miss or mis-address them."""
+        mine = {id(p) for p in self.members} | {id(p) for p in self.dense}
+        now = {id(p) for p in model.parameters() if p.requires_grad}
+        if mine != now:
+            raise RuntimeError(f"TrainableArena is stale: {len(now - mine)} trainable parameter(s) not covered, {len(mine - now)} no longer trainable; "
+                               "build the arena after the model is final")
+        for p in self.members:
+            fi, o, n = self._slot_of[id(p)]
+            P = self.flat[fi]
+            if p.device != P.device or p.data_ptr() != P.data_ptr() + o * P.element_size():
+                raise RuntimeError("TrainableArena is stale: a member parameter no longer aliases the arena (was the model moved or re-materialised?)")
 
     def grad_view(self, p: nn.Parameter) -> Tensor:
         G, o, n = p._llx_slot

@@ -24,6 +24,8 @@ class Trainer:
                  clip_grad_norm: Optional[float] = None, n_buckets: int = 4):
         self.model, self.optim, self.lr_schedule = model, optim, lr_schedule
         self.grad_accum, self.clip = grad_accum, clip_grad_norm
+        if self._arena() is not None:
+            self._arena().verify(model)
         self.buckets = GradBuckets(model, n_buckets=n_buckets)
         self.step_idx = 0
         self.n_toks = torch.zeros((), dtype=torch.int64)

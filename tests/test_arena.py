@@ -51,6 +51,14 @@ def test_arena_layout_and_views():
     with torch.no_grad():
         P.add_(1.0)  # an update of the flat parameter IS an update of the members
     assert torch.equal(m.lora_a, before["lora_a"] + 1.0)
+    arena.verify(m)
+    m.weight.requires_grad_(True)  # a parameter turned trainable behind the arena's back
+    try:
+        arena.verify(m)
+        raise AssertionError("verify() must notice the uncovered parameter")
+    except RuntimeError as e:
+        assert "stale" in str(e)
+    m.weight.requires_grad_(False)
     # buckets of the exchange: adjacent members merge into one slice
     assert len(arena.ranges([m.lora_a, m.lora_b, m.gain])) == 1 and len(arena.ranges([m.lora_a, m.gain])) == 2
 
