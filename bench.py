@@ -13,6 +13,10 @@ import os
 import sys
 import time
 
+# the host driver of this pool only supports dmabuf IPC: RCCL's device-memory sharing across the ranks of a node needs it (the launcher's
+# environment normally carries it already; a bare shell may not)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "llama-x_amd"))
 sys.path.insert(0, ROOT)
@@ -236,15 +240,21 @@ def run_workload(args, config: str, device, world: int, rank: int, steps: int, w
         step = eager_step
         launch_mode = "eager, 4 backward stages, RCCL all-reduce of stage k under the backward of stage k-1"
         if use_graph:
-            stepper.capture(ids_buf)
+            try:
+                stepper.capture(ids_buf)
 
-            def step():
-                ids, labels = batch()
-                ids_buf.copy_(ids)
-                labels_buf.copy_(labels)
-                return stepper(ids_buf)
+                def step():
+                    ids, labels = batch()
+                    ids_buf.copy_(ids)
+                    labels_buf.copy_(labels)
+                    return stepper(ids_buf)
 
-            launch_mode = "hipGraph replay per stage (fwd | 4 x bwd | AdamW), RCCL all-reduce of stage k under the backward of stage k-1"
+                launch_mode = "hipGraph replay per stage (fwd | 4 x bwd | AdamW), RCCL all-reduce of stage k under the backward of stage k-1"
+            except Exception as exc:  # noqa: BLE001 - a capture problem must not cost the measurement: the same stages run eagerly
+                print(f"[bench] rank {rank}: stage capture failed ({type(exc).__name__}: {exc}); running the stages eagerly", file=sys.stderr, flush=True)
+                torch.cuda.synchronize()
+                stepper._graphs = None
+                step = eager_step
     else:
         buckets = GradBuckets(model, n_buckets=4, force=False, overlap=False)  # single replica: inactive, .grad stays with autograd
 
