@@ -13,7 +13,7 @@ from oracle import ref as O  # noqa: E402
 from tests.util import bf16_params, build_model  # noqa: E402
 
 
-def _setup(cuda, n_layers=3, kv_heads=1):
+def _setup(cuda, n_layers=3, kv_heads=1, quantize=None):
     cfg = O.TINY._replace(num_layers=n_layers, num_kv_heads=kv_heads)
     p = O.init_params(cfg)
     p.update(O.init_lora(cfg, 8))
@@ -24,7 +24,7 @@ def _setup(cuda, n_layers=3, kv_heads=1):
         batches.append((t, torch.roll(t, -1, 1)))
 
     def make():
-        model = build_model(cfg, pb, cuda, lora_rank=8)
+        model = build_model(cfg, pb, cuda, lora_rank=8, quantize=quantize, quantize_kwargs=dict(dynamic_int8_act=True) if quantize else None)
         for n, q in model.named_parameters():
             q.requires_grad_("lora_" in n or n.endswith("norm.weight"))
         return model
@@ -68,12 +68,14 @@ def test_backward_writes_gradients_in_place(cuda):
             assert p.grad.data_ptr() == gv(p).data_ptr() and torch.equal(p.grad, r.grad), n
 
 
-@pytest.mark.parametrize("mode", ["eager", "graph"])
+@pytest.mark.parametrize("mode", ["eager", "graph", "eager-int8"])
 def test_flat_adamw_step_is_bit_identical(cuda, mode):
     from llx.arena import TrainableArena
     from llx.dp import GradBuckets
 
-    _, make, batches = _setup(cuda)
+    # "-int8": INT8 base with dynamically quantised activations + bf16 LoRA (BASELINE configs[3]); two kv heads = the in-place route for all
+    _, make, batches = _setup(cuda, kv_heads=2, quantize="int8") if mode.endswith("int8") else _setup(cuda)
+    mode = mode.split("-")[0]
     ref = make()
     opt_ref = _adamw([p for p in ref.parameters() if p.requires_grad])
     ref_losses = []
@@ -130,7 +132,8 @@ def test_flat_adamw_step_is_bit_identical(cuda, mode):
     torch.cuda.synchronize()
     assert losses == ref_losses, (losses, ref_losses)
     for (n, p), (_, r) in zip(model.named_parameters(), ref.named_parameters()):
-        assert torch.equal(p, r), n
+        if p.requires_grad:  # (the frozen Int8LinearWeight base has no aten.equal, as in the reference)
+            assert torch.equal(p, r), n
 
 
 def test_staged_step_on_arena_buckets(cuda):
