@@ -9,7 +9,8 @@
 // QUANT: the bf16 output row is also quantised row-wise to int8 (quantize_int8_rowwise of subclasses/int8.py:10-16 applied to y, as
 // _Int8Linear does to its input at :110-113 when dynamic_int8_act is set): absmax of the ROUNDED outputs / 127 in fp32, IEEE divide,
 // round half to even - bit-identical to llx_quantize_int8_rowwise(y), without reading y back.
-template <int NCH, bool QUANT = false>
+// FULL: dim == NCH * 512 (no per-chunk guards: the loads of a row are issued back to back)
+template <int NCH, bool QUANT = false, bool FULL = false>
 __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
                                                           bf16_t* __restrict__ y, float* __restrict__ rstd_out,
                                                           int64_t rows, int dim, float eps, int8_t* __restrict__ q = nullptr,
@@ -23,7 +24,7 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const bf16_t* __restri
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
     const int col = c * 512 + lane * 8;
-    if (col < dim) {
+    if (FULL || col < dim) {
       v[c] = *reinterpret_cast<const u32x4_t*>(xr + col);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -40,7 +41,7 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const bf16_t* __restri
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
     const int col = c * 512 + lane * 8;
-    if (col < dim) {
+    if (FULL || col < dim) {
       u32x4_t wv = *reinterpret_cast<const u32x4_t*>(w + col);
       u32x4_t o;
 #pragma unroll
@@ -63,7 +64,7 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const bf16_t* __restri
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       const int col = c * 512 + lane * 8;
-      if (col < dim) {
+      if (FULL || col < dim) {
         u32x2_t o = {0u, 0u};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -81,12 +82,15 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const bf16_t* __restri
 // w, w+4, ...; lane l owns columns {c*512 + l*8 .. +8}.  dx is written per row; the per-lane dw partial sums stay in
 // registers, are combined across the 4 waves through LDS and written once per block to dw_partial[blockIdx][dim] (fp32).
 //   xhat = x*rstd ; g = dy*w ; dx = rstd * (g - xhat * mean(g*xhat)) [+ dres] ; dw = sum_rows(dy*xhat)
-template <int NCH>
+// FULL: dim == NCH * 512 - every chunk of every lane is inside the row, the per-chunk guards (and the basic-block boundaries they put
+// between the loads, which made the compiler drain vmcnt to 0 before every prefetch) compile away.
+template <int NCH, bool FULL = false, int RES = -1>  // RES: 1 / 0 = dres known present / absent at compile time (FULL kernels), -1 = runtime
 __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
                                                           const bf16_t* __restrict__ w, const float* __restrict__ rstd,
                                                           bf16_t* __restrict__ dx, float* __restrict__ dw_partial,
                                                           const bf16_t* __restrict__ dres, int64_t rows, int dim, int rows_per_block) {
   extern __shared__ __attribute__((aligned(16))) float dwsh[];  // [dim] when dw is requested
+  const bool has_res = RES < 0 ? dres != nullptr : RES == 1;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   u32x4_t wp[NCH];  // norm weight, kept packed (unpacked where it is used)
   float dwacc[NCH][8];
@@ -96,7 +100,7 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restri
 #pragma unroll
     for (int e = 0; e < 8; ++e) dwacc[c][e] = 0.f;
     wp[c] = u32x4_t{0u, 0u, 0u, 0u};
-    if (col < dim) wp[c] = *reinterpret_cast<const u32x4_t*>(w + col);
+    if (FULL || col < dim) wp[c] = *reinterpret_cast<const u32x4_t*>(w + col);
   }
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
   const int64_t r_end = (r0 + rows_per_block < rows) ? r0 + rows_per_block : rows;
@@ -109,10 +113,10 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restri
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       const int col = c * 512 + lane * 8;
-      if (col < dim) {
+      if (FULL || col < dim) {
         R.x[c] = *reinterpret_cast<const u32x4_t*>(x + row * dim + col);
         R.d[c] = *reinterpret_cast<const u32x4_t*>(dy + row * dim + col);
-        if (dres) R.r[c] = *reinterpret_cast<const u32x4_t*>(dres + row * dim + col);
+        if (has_res) R.r[c] = *reinterpret_cast<const u32x4_t*>(dres + row * dim + col);
       }
     }
   };
@@ -122,7 +126,7 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restri
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       const int col = c * 512 + lane * 8;
-      if (col < dim) {
+      if (FULL || col < dim) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const float x0 = bflo(R.x[c][e]) * rs, x1 = bfhi(R.x[c][e]) * rs;
@@ -137,7 +141,7 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restri
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       const int col = c * 512 + lane * 8;
-      if (col < dim) {
+      if (FULL || col < dim) {
         u32x4_t o;
         // opaque copy: without it hipcc keeps the 64 unpacked, scaled floats of the first pass alive instead of the 16 packed
         // registers (512 VGPRs + scratch with two row sets in flight)
@@ -147,7 +151,7 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restri
           const float x0 = bflo(R.x[c][e]) * rs, x1 = bfhi(R.x[c][e]) * rs;
           float a = rs * (bflo(R.d[c][e]) * bflo(wp[c][e]) - x0 * m);
           float b = rs * (bfhi(R.d[c][e]) * bfhi(wp[c][e]) - x1 * m);
-          if (dres) {  // gradient of the residual branch joins here: bf16(dx) + dres, rounded as the eager add would
+          if (has_res) {  // gradient of the residual branch joins here: bf16(dx) + dres, rounded as the eager add would
             a = bf2f(f2bf(a)) + bflo(R.r[c][e]);
             b = bf2f(f2bf(b)) + bfhi(R.r[c][e]);
           }
@@ -185,7 +189,7 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restri
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
           const int col = c * 512 + lane * 8;
-          if (col < dim) {
+          if (FULL || col < dim) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) dwsh[col + e] = (wsel == 0 ? 0.f : dwsh[col + e]) + dwacc[c][e];
           }
@@ -229,7 +233,10 @@ extern "C" int llx_rmsnorm_fwd(const void* x, const void* w, void* y, float* rst
   const dim3 grid((unsigned)cdiv64(rows, 4)), block(256);
   const int nch = (int)cdiv64(dim, 512);
 #define L(N) hipLaunchKernelGGL((rmsnorm_fwd_kernel<N, false>), grid, block, 0, stream, (const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y, rstd, rows, (int)dim, eps, (int8_t*)nullptr, (int64_t)0, (bf16_t*)nullptr)
-  if (nch <= 1) L(1); else if (nch <= 2) L(2); else if (nch <= 4) L(4); else if (nch <= 8) L(8); else L(16);
+#define LF(N) hipLaunchKernelGGL((rmsnorm_fwd_kernel<N, false, true>), grid, block, 0, stream, (const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y, rstd, rows, (int)dim, eps, (int8_t*)nullptr, (int64_t)0, (bf16_t*)nullptr)
+  if (dim == 4096) LF(8); else if (dim == 2048) LF(4); else if (dim == 8192) LF(16);
+  else if (nch <= 1) L(1); else if (nch <= 2) L(2); else if (nch <= 4) L(4); else if (nch <= 8) L(8); else L(16);
+#undef LF
 #undef L
   LLX_LAUNCH_CHECK("llx_rmsnorm_fwd");
   return LLX_OK;
@@ -245,7 +252,10 @@ extern "C" int llx_rmsnorm_fwd_quant(const void* x, const void* w, void* y, floa
   const dim3 grid((unsigned)cdiv64(rows, 4)), block(256);
   const int nch = (int)cdiv64(dim, 512);
 #define L(N) hipLaunchKernelGGL((rmsnorm_fwd_kernel<N, true>), grid, block, 0, stream, (const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y, rstd, rows, (int)dim, eps, (int8_t*)q, ldq, (bf16_t*)qscale)
-  if (nch <= 1) L(1); else if (nch <= 2) L(2); else if (nch <= 4) L(4); else if (nch <= 8) L(8); else L(16);
+#define LF(N) hipLaunchKernelGGL((rmsnorm_fwd_kernel<N, true, true>), grid, block, 0, stream, (const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y, rstd, rows, (int)dim, eps, (int8_t*)q, ldq, (bf16_t*)qscale)
+  if (dim == 4096) LF(8); else if (dim == 2048) LF(4); else if (dim == 8192) LF(16);
+  else if (nch <= 1) L(1); else if (nch <= 2) L(2); else if (nch <= 4) L(4); else if (nch <= 8) L(8); else L(16);
+#undef LF
 #undef L
   LLX_LAUNCH_CHECK("llx_rmsnorm_fwd_quant");
   return LLX_OK;
@@ -273,7 +283,12 @@ extern "C" int llx_rmsnorm_bwd(const void* dy, const void* x, const void* w, con
   float* part = dw ? (float*)workspace : nullptr;
   const size_t lds = dw ? (size_t)dim * 4 : 0;
 #define L(N) hipLaunchKernelGGL(rmsnorm_bwd_kernel<N>, dim3(nblk), dim3(256), lds, stream, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)w, rstd, (bf16_t*)dx, part, (const bf16_t*)dres, rows, (int)dim, rpb)
-  if (nch <= 1) L(1); else if (nch <= 2) L(2); else if (nch <= 4) L(4); else if (nch <= 8) L(8); else L(16);
+#define LF(N) if (dres) LFR(N, 1); else LFR(N, 0)
+#define LFR(N, R) hipLaunchKernelGGL((rmsnorm_bwd_kernel<N, true, R>), dim3(nblk), dim3(256), lds, stream, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)w, rstd, (bf16_t*)dx, part, (const bf16_t*)dres, rows, (int)dim, rpb)
+  if (dim == 4096) { LF(8); } else if (dim == 2048) { LF(4); } else if (dim == 8192) { LF(16); }
+  else if (nch <= 1) L(1); else if (nch <= 2) L(2); else if (nch <= 4) L(4); else if (nch <= 8) L(8); else L(16);
+#undef LFR
+#undef LF
 #undef L
   LLX_LAUNCH_CHECK("llx_rmsnorm_bwd");
   if (dw) {
