@@ -413,8 +413,28 @@ __global__ void skinny_tn_reduce_many_kernel(const TnRedMany m) {
     n = (int)(idx % d.N);
     dst = d.transpose_out ? d.out + (int64_t)n * d.out_ld + r : d.out + (int64_t)r * d.out_ld + n;
   }
+  // the partials of one output are nsplit loads RP * N floats apart: eight are requested together, then added in split order (the
+  // same sum as a plain loop - which the compiler turns into load, wait, add per split: 24 exposed memory latencies per thread)
   float sum = 0.f;
-  for (int p = 0; p < d.nsplit; ++p) sum += d.partial[((int64_t)p * d.RP + r) * d.N + n];
+  const float* src = d.partial + (int64_t)r * d.N + n;
+  const int64_t stride = (int64_t)d.RP * d.N;
+  int p = 0;
+  for (; p + 8 <= d.nsplit; p += 8) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = src[(p + j) * stride];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sum += v[j];
+  }
+  if (p + 4 <= d.nsplit) {
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = src[(p + j) * stride];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sum += v[j];
+    p += 4;
+  }
+  for (; p < d.nsplit; ++p) sum += src[p * stride];
   sum *= d.scale;
   if (d.accumulate) sum += bf2f(*dst);
   *dst = f2bf(sum);
