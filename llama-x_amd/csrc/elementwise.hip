@@ -294,7 +294,8 @@ extern "C" int llx_lora_pack(const void* in, int64_t ld, void* out, int64_t out_
 //   bT    [R, N]      block (r_off_i.., n_off_i..) = lora_b_i^T       (B operand of u = dy @ B_blk)
 //   a2t   [K, 64]     cols r_off_i.. = s * lora_a_i^T                 (K-extension operand of the dgrad GEMM)
 struct LoraMember { const bf16_t* a; const bf16_t* b; int N, n_off, r, r_off; };
-struct LoraGroup { LoraMember m[4]; int nm, K, N, R; float scale; bf16_t* a_cat; bf16_t* b2; bf16_t* bT; bf16_t* a2t; };
+struct LoraGroup { LoraMember m[4]; int nm, K, N, R; float scale; bf16_t* a_cat; bf16_t* b2; bf16_t* bT; bf16_t* a2t;
+                   int aligned8; /* every member's rank and rank offset are multiples of 8: an 8-element chunk never straddles members */ };
 
 // One thread = 8 consecutive elements of one image row (one 16-byte store); K % 8 == 0 and N % 8 == 0 (checked by the launcher).
 __device__ __forceinline__ void lora_group_pack_body(const LoraGroup& g) {
@@ -310,6 +311,61 @@ __device__ __forceinline__ void lora_group_pack_body(const LoraGroup& g) {
     return;
   }
   idx -= n_acat;
+  if (g.aligned8) {
+    // chunks never straddle members: pick the member first, then load without per-element conditions - the element-wise form below
+    // compiles to load, wait, load, wait ... (eight exposed latencies per thread)
+    if (idx < n_b2) {  // b2[n][c0..c0+8): 16 contiguous bytes of the member's lora_b row, scaled
+      const int n = (int)(idx >> 3), c0 = (int)(idx & 7) * 8;
+      u32x4_t o = {0u, 0u, 0u, 0u};
+      for (int i = 0; i < g.nm; ++i) {
+        const LoraMember& m = g.m[i];
+        if (n >= m.n_off && n < m.n_off + m.N && c0 >= m.r_off && c0 < m.r_off + m.r) {
+          const u32x4_t v = *reinterpret_cast<const u32x4_t*>(m.b + (int64_t)(n - m.n_off) * m.r + (c0 - m.r_off));
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = pack_bf2(bflo(v[e]) * g.scale, bfhi(v[e]) * g.scale);
+        }
+      }
+      *reinterpret_cast<u32x4_t*>(g.b2 + (int64_t)n * 64 + c0) = o;
+      return;
+    }
+    idx -= n_b2;
+    if (idx < n_bT) {  // bT[r][n0..n0+8): eight lora_b elements one row apart
+      const int nc = g.N / 8;
+      const int r = (int)(idx / nc), n0 = (int)(idx % nc) * 8;
+      u32x4_t o = {0u, 0u, 0u, 0u};
+      for (int i = 0; i < g.nm; ++i) {
+        const LoraMember& m = g.m[i];
+        if (r >= m.r_off && r < m.r_off + m.r && n0 >= m.n_off && n0 < m.n_off + m.N) {
+          const bf16_t* src = m.b + (int64_t)(n0 - m.n_off) * m.r + (r - m.r_off);
+          bf16_t v[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = src[(int64_t)e * m.r];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = (uint32_t)v[2 * e] | ((uint32_t)v[2 * e + 1] << 16);
+        }
+      }
+      *reinterpret_cast<u32x4_t*>(g.bT + (int64_t)r * g.N + n0) = o;
+      return;
+    }
+    idx -= n_bT;
+    if (idx < n_a2t) {  // a2t[k][c0..c0+8): eight lora_a elements one row (K) apart, scaled
+      const int k = (int)(idx >> 3), c0 = (int)(idx & 7) * 8;
+      u32x4_t o = {0u, 0u, 0u, 0u};
+      for (int i = 0; i < g.nm; ++i) {
+        const LoraMember& m = g.m[i];
+        if (c0 >= m.r_off && c0 < m.r_off + m.r) {
+          const bf16_t* src = m.a + (int64_t)(c0 - m.r_off) * g.K + k;
+          bf16_t v[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = src[(int64_t)e * g.K];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = pack_bf2(bf2f(v[2 * e]) * g.scale, bf2f(v[2 * e + 1]) * g.scale);
+        }
+      }
+      *reinterpret_cast<u32x4_t*>(g.a2t + (int64_t)k * 64 + c0) = o;
+    }
+    return;
+  }
   if (idx < n_b2) {  // b2[n][c0..c0+8) = s * lora_b_i[n - n_off][c - r_off]
     const int n = (int)(idx >> 3), c0 = (int)(idx & 7) * 8;
     float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -385,6 +441,9 @@ static int lora_fill_group(LoraGroup& g, const void* const* lora_a, const void* 
   }
   LLX_REQUIRE(r_off <= 64, "llx_lora_group_pack: total rank %d > 64", r_off);
   g.nm = nm; g.K = (int)K; g.N = n_off; g.R = r_off; g.scale = scale;
+  g.aligned8 = 1;
+  for (int i = 0; i < nm; ++i)
+    if (g.m[i].r % 8 != 0 || g.m[i].r_off % 8 != 0 || ((uintptr_t)lora_b[i] & 15) != 0) g.aligned8 = 0;
   g.a_cat = (bf16_t*)a_cat; g.b2 = (bf16_t*)b2; g.bT = (bf16_t*)bT; g.a2t = (bf16_t*)a2t;
   LLX_REQUIRE(K % 8 == 0, "llx_lora_group_pack: K=%lld must be a multiple of 8", (long long)K);
   for (int i = 0; i < nm; ++i) LLX_REQUIRE(Ns[i] % 8 == 0, "llx_lora_group_pack: member %d: N=%lld must be a multiple of 8", i, (long long)Ns[i]);

@@ -973,3 +973,33 @@ def test_skinny_nt_with_scaled_copy(K, cuda, M, Kd, R, ranged):
     u, g = K.skinny_nt(x, w, kr, colscale=cs)
     assert torch.equal(u, u0)
     assert torch.equal(g, K.scale(x, colscale=cs))
+
+
+@pytest.mark.parametrize("Ns,ranks,Kd", [((512, 128, 128), (16, 16, 16), 512), ((1792, 1792), (8, 24), 512), ((256,), (12,), 256), ((512, 256), (4, 12), 384)])
+def test_lora_operand_images(K, cuda, Ns, ranks, Kd):
+    """llx_lora_group_pack / llx_lora_groups_pack: a_cat = [A_i], b2 = s * block-diagonal [B_i] padded to 64 columns, bT = block-diagonal
+    [B_i]^T, a2t = s * [A_i]^T padded to 64 columns - against torch, for ranks that keep 8-element chunks inside a member (the vector
+    path) and for ranks that do not (the element path); the grouped launch gives the same images."""
+    s = 0.75
+    As = [_bf(O.randn(f"pk_a{i}", (r, Kd))).to(cuda) for i, r in enumerate(ranks)]
+    Bs = [_bf(O.randn(f"pk_b{i}", (n, r))).to(cuda) for i, (n, r) in enumerate(zip(Ns, ranks))]
+    N, R = sum(Ns), sum(ranks)
+    a_cat, b2, bT, a2t = K.lora_group_pack(As, Bs, Kd, s)
+    want_a = torch.cat(As, 0)
+    assert torch.equal(a_cat, want_a)
+    want_b2 = torch.zeros(N, 64, device=cuda, dtype=torch.bfloat16)
+    want_bT = torch.zeros(R, N, device=cuda, dtype=torch.bfloat16)
+    no = ro = 0
+    for b, n, r in zip(Bs, Ns, ranks):
+        want_b2[no : no + n, ro : ro + r] = (b.float() * s).bfloat16()
+        want_bT[ro : ro + r, no : no + n] = b.T
+        no += n
+        ro += r
+    assert torch.equal(b2, want_b2) and torch.equal(bT, want_bT)
+    want_a2t = torch.zeros(Kd, 64, device=cuda, dtype=torch.bfloat16)
+    want_a2t[:, :R] = (want_a.float() * s).bfloat16().T
+    assert torch.equal(a2t, want_a2t)
+    both = K.lora_groups_pack([(As, Bs, Kd, s), (As[:1], Bs[:1], Kd, 2 * s)])
+    for got, want in zip(both[0], (a_cat, b2, bT, a2t)):
+        assert torch.equal(got, want)
+    assert torch.equal(both[1][0], As[0]) and torch.equal(both[1][2], Bs[0].T.contiguous())
