@@ -127,6 +127,18 @@ __device__ __forceinline__ void swiglu_bwd8(const u32x4_t& dv, const u32x4_t& gv
 
 // ---- RoPE on 8 packed bf16 elements = 4 interleaved pairs (modelling/llama.py:63-73): tp -> table[(s*64 + j)*2] for the first
 // pair j of the chunk (fp32 cos, sin interleaved); sign = +1 forward, -1 backward (rotation by -theta is the exact transpose).
+__device__ __forceinline__ u32x4_t rope8(const u32x4_t& v, const f32x4_t& t0, const f32x4_t& t1, float sign) {  // table values preloaded
+  const float cs[4] = {t0[0], t0[2], t1[0], t1[2]};
+  const float sn[4] = {t0[1] * sign, t0[3] * sign, t1[1] * sign, t1[3] * sign};
+  u32x4_t o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float x0 = bflo(v[e]), x1 = bfhi(v[e]);
+    o[e] = pack_bf2(x0 * cs[e] - x1 * sn[e], x1 * cs[e] + x0 * sn[e]);
+  }
+  return o;
+}
+
 __device__ __forceinline__ u32x4_t rope8(const u32x4_t& v, const float* __restrict__ tp, float sign) {
   const f32x4_t t0 = *reinterpret_cast<const f32x4_t*>(tp);
   const f32x4_t t1 = *reinterpret_cast<const f32x4_t*>(tp + 4);

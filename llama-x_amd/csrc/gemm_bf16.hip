@@ -403,49 +403,78 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const GemmArgs g) {
     }
     return;
   }
-#pragma unroll 4
-  for (int it = 0; it < BNT / 16; ++it) {
-    const int q = it * 512 + tid;
-    const int row = q / (BNT / 8), cc = q % (BNT / 8);
-    const int gm = m0 + row, gn = n0 + cc * 8;
-    if (gm < g.M && gn < g.col_end) {
-      u32x4_t v = *reinterpret_cast<const u32x4_t*>(smem + row * EROW + cc * 16);
-      if constexpr (EPI == EPI_RESIDUAL) {
-        // reference rounding: the linear's bf16 output is added to the bf16 residual (modelling/llama.py:172-173)
-        u32x4_t r = *reinterpret_cast<const u32x4_t*>(g.E + (int64_t)gm * g.lde + gn);
+  // Two phases per batch of iterations: first every operand the epilogue needs from global memory (residual, gate|up, bias, scale,
+  // RoPE table) is requested from a clamped - always valid - address, with no branch in between, then the tile rows are read back from
+  // LDS, combined and stored.  With the load inside the bounds check every iteration was its own basic block: load, s_waitcnt vmcnt(0),
+  // store, sixteen times in a row - sixteen exposed memory latencies per tile.
+  constexpr int NIT = BNT / 16;
+  constexpr int EB = (EPI == EPI_SWIGLU_BWD || EPI == EPI_ROPE) ? 4 : 8;
+  constexpr bool AUX = EPI == EPI_RESIDUAL || EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_SWIGLU_BWD || EPI == EPI_ROPE || EPI == EPI_COLSCALE;
+#pragma unroll 1
+  for (int it0 = 0; it0 < NIT; it0 += EB) {
+    u32x4_t aux0[EB], aux1[EB];
+    if constexpr (AUX) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = pack_bf2(bflo(v[e]) + bflo(r[e]), bfhi(v[e]) + bfhi(r[e]));
-      } else if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) {
-        u32x4_t b = *reinterpret_cast<const u32x4_t*>(g.E + gn);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float lo = bflo(v[e]) + bflo(b[e]), hi = bfhi(v[e]) + bfhi(b[e]);
-          if constexpr (EPI == EPI_BIAS_GELU) {
-            lo = gelu_erf(bf2f(f2bf(lo)));
-            hi = gelu_erf(bf2f(f2bf(hi)));
-          }
-          v[e] = pack_bf2(lo, hi);
+      for (int j = 0; j < EB; ++j) {
+        const int q = (it0 + j) * 512 + tid;
+        const int row = q / (BNT / 8), cc = q % (BNT / 8);
+        const int gmc = min(m0 + row, g.M - 1), gnc = min(n0 + cc * 8, g.col_end - 8);
+        if constexpr (EPI == EPI_RESIDUAL) {
+          aux0[j] = *reinterpret_cast<const u32x4_t*>(g.E + (int64_t)gmc * g.lde + gnc);
+        } else if constexpr (EPI == EPI_SWIGLU_BWD) {
+          aux0[j] = *reinterpret_cast<const u32x4_t*>(g.E + (int64_t)gmc * g.lde + gnc);
+          aux1[j] = *reinterpret_cast<const u32x4_t*>(g.E + (int64_t)gmc * g.lde + g.N + gnc);
+        } else if constexpr (EPI == EPI_ROPE) {
+          const float* tp = g.rope + ((int64_t)(gmc % g.rope_S) * 64 + ((gnc & 127) >> 1)) * 2;
+          aux0[j] = *reinterpret_cast<const u32x4_t*>(tp);
+          aux1[j] = *reinterpret_cast<const u32x4_t*>(tp + 4);
+        } else {  // bias / column scale: E[N]
+          aux0[j] = *reinterpret_cast<const u32x4_t*>(g.E + gnc);
         }
-      } else if constexpr (EPI == EPI_SWIGLU_BWD) {
-        // the product is dh = dL/d(silu(g)*u); what leaves the kernel is dg | du (SwiGLU backward fused: dh never reaches HBM).
-        // v holds dh rounded to bf16 exactly as the stand-alone GEMM would have stored it.
-        const u32x4_t gv = *reinterpret_cast<const u32x4_t*>(g.E + (int64_t)gm * g.lde + gn);
-        const u32x4_t uv = *reinterpret_cast<const u32x4_t*>(g.E + (int64_t)gm * g.lde + g.N + gn);
-        u32x4_t og, ou;
-        swiglu_bwd8(v, gv, uv, og, ou);
-        *reinterpret_cast<u32x4_t*>(g.C + (int64_t)gm * g.ldc + g.N + gn) = ou;
-        v = og;
-      } else if constexpr (EPI == EPI_ROPE) {
-        // q|k|v projection: apply_rope on the q and k heads right here (modelling/llama.py:118-125); v holds the bf16-rounded
-        // projection exactly as the stand-alone GEMM would have stored it, the rotation is the one of rope_kernel
-        if (gn < g.rope_cols) v = rope8(v, g.rope + ((int64_t)(gm % g.rope_S) * 64 + ((gn & 127) >> 1)) * 2, 1.f);
-      } else if constexpr (EPI == EPI_COLSCALE) {
-        // weight-only int8: (x @ W_i8^T) rounded to bf16, then * scale[n] (subclasses/int8.py:118)
-        u32x4_t s = *reinterpret_cast<const u32x4_t*>(g.E + gn);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = pack_bf2(bflo(v[e]) * bflo(s[e]), bfhi(v[e]) * bfhi(s[e]));
       }
-      *reinterpret_cast<u32x4_t*>(g.C + (int64_t)gm * g.ldc + gn) = v;
+    }
+#pragma unroll
+    for (int j = 0; j < EB; ++j) {
+      const int q = (it0 + j) * 512 + tid;
+      const int row = q / (BNT / 8), cc = q % (BNT / 8);
+      const int gm = m0 + row, gn = n0 + cc * 8;
+      if (gm < g.M && gn < g.col_end) {
+        u32x4_t v = *reinterpret_cast<const u32x4_t*>(smem + row * EROW + cc * 16);
+        if constexpr (EPI == EPI_RESIDUAL) {
+          // reference rounding: the linear's bf16 output is added to the bf16 residual (modelling/llama.py:172-173)
+          const u32x4_t r = aux0[j];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = pack_bf2(bflo(v[e]) + bflo(r[e]), bfhi(v[e]) + bfhi(r[e]));
+        } else if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) {
+          const u32x4_t bb = aux0[j];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float lo = bflo(v[e]) + bflo(bb[e]), hi = bfhi(v[e]) + bfhi(bb[e]);
+            if constexpr (EPI == EPI_BIAS_GELU) {
+              lo = gelu_erf(bf2f(f2bf(lo)));
+              hi = gelu_erf(bf2f(f2bf(hi)));
+            }
+            v[e] = pack_bf2(lo, hi);
+          }
+        } else if constexpr (EPI == EPI_SWIGLU_BWD) {
+          // the product is dh = dL/d(silu(g)*u); what leaves the kernel is dg | du (SwiGLU backward fused: dh never reaches HBM).
+          // v holds dh rounded to bf16 exactly as the stand-alone GEMM would have stored it.
+          u32x4_t og, ou;
+          swiglu_bwd8(v, aux0[j], aux1[j], og, ou);
+          *reinterpret_cast<u32x4_t*>(g.C + (int64_t)gm * g.ldc + g.N + gn) = ou;
+          v = og;
+        } else if constexpr (EPI == EPI_ROPE) {
+          // q|k|v projection: apply_rope on the q and k heads right here (modelling/llama.py:118-125); v holds the bf16-rounded
+          // projection exactly as the stand-alone GEMM would have stored it, the rotation is the one of rope_kernel
+          if (gn < g.rope_cols) v = rope8(v, __builtin_bit_cast(f32x4_t, aux0[j]), __builtin_bit_cast(f32x4_t, aux1[j]), 1.f);
+        } else if constexpr (EPI == EPI_COLSCALE) {
+          // weight-only int8: (x @ W_i8^T) rounded to bf16, then * scale[n] (subclasses/int8.py:118)
+          const u32x4_t sc = aux0[j];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = pack_bf2(bflo(v[e]) * bflo(sc[e]), bfhi(v[e]) * bfhi(sc[e]));
+        }
+        *reinterpret_cast<u32x4_t*>(g.C + (int64_t)gm * g.ldc + gn) = v;
+      }
     }
   }
 }
