@@ -27,7 +27,7 @@ extern "C" {
 typedef void* llx_stream_t; /* hipStream_t */
 
 /* ---- library ------------------------------------------------------------------------------------------------ */
-int llx_version(void);                                   /* 101 = 0.1.1 */
+int llx_version(void);                                   /* 102 = 0.1.2 */
 const char* llx_last_error_string(void);                 /* thread-local, valid until the next failing call */
 int llx_device_info(int device, char* name, int len);    /* returns CU count, fills gcn arch name */
 
@@ -87,6 +87,9 @@ int llx_gemm_tn_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, voi
  *      scales bf16; C bf16 = (int32 acc) * a_scale[m] * b_scale[n], one rounding.  K multiple of 128. ----------- */
 int llx_int8_mm_dequant(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
                         const void* a_scale, const void* b_scale, llx_stream_t s);
+/* fp32 scales -> fp32 C (the op returns dtype = A_scale.dtype: subclasses/int8_mm.py:126,136,143); ldc in fp32 elements. */
+int llx_int8_mm_dequant_f32(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
+                            const float* a_scale, const float* b_scale, llx_stream_t s);
 /* The same with the neighbours of its call sites fused in (int8 base, dynamically quantised activations - subclasses/int8.py:110-118):
  * C = epilogue( bf16( bf16(int8_mm_dequant(A, B, a_scale, b_scale)) + A2[M,K2].B2[N,K2]^T ) ).  A2/B2 (nullable; bf16, K2 % 64 == 0):
  * the LoRA adapter (modelling/lora.py:43) - the int32 accumulators are dequantised in place, the extension accumulates on top in fp32.
@@ -105,10 +108,6 @@ int llx_quantize_int8_rowwise(const void* x, int64_t ldx, void* q, int64_t ldq, 
  *      (README.md:16): allow(q,k) = (k <= q || k < prefix_len[b]) && (!doc_ids || doc_ids[b,q] == doc_ids[b,k]).
  *      q [B,S,H,128], k/v [B,S,KVH,128] with free batch/sequence strides; lse fp32 [B,H,S] (log2 units).
  *      flags: tile classes built by llx_attn_tile_flags (needed only with doc_ids / prefix_len). ----------------- */
-int llx_debug_attn_fwd_stamps(const void* q, const void* k, const void* v, void* o, int64_t S, int64_t H, int64_t KVH,
-                              unsigned long long* stamps, llx_stream_t s); /* diagnostic: in-kernel s_memtime stamps, timing only */
-int llx_debug_attn_bwd_set_stamps(unsigned long long* stamps); /* diagnostic: stamp build of the dK/dV kernel for the next llx_attn_bwd calls */
-int llx_debug_attn_fwd_occupancy(void); /* diagnostic: workgroups per CU granted to the forward kernel */
 int64_t llx_attn_flags_bytes(int64_t B, int64_t S);
 int llx_attn_tile_flags(const int* doc_ids, const int* prefix_len, void* flags, int64_t B, int64_t S, llx_stream_t s);
 int llx_attn_fwd(const void* q, int64_t q_sb, int64_t q_ss, const void* k, int64_t k_sb, int64_t k_ss, const void* v, int64_t v_sb,

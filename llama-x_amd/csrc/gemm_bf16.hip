@@ -13,6 +13,7 @@
 #include "common.h"
 #include <type_traits>
 #include <stdlib.h>
+#include <mutex>
 
 #define BM 256
 #define BN 256
@@ -24,7 +25,7 @@
 // BNT = 128: the "half tile" (256 rows x 128 columns, waves 4 x 2, 64 x 64 per wave) used for the columns a 256-wide grid would leave
 // to a partly empty last round (see gemm_nt_bf16_impl); same LDS stage layout with a half-size B tile.
 
-enum { EPI_NONE = 0, EPI_RESIDUAL = 1, EPI_BIAS = 2, EPI_BIAS_GELU = 3, EPI_COLSCALE = 4, EPI_ROWCOLSCALE = 5, EPI_SWIGLU_BWD = 6, EPI_SWIGLU_FWD = 7, EPI_ROPE = 8, EPI_SPLITK = 9 };
+enum { EPI_NONE = 0, EPI_RESIDUAL = 1, EPI_BIAS = 2, EPI_BIAS_GELU = 3, EPI_COLSCALE = 4, EPI_ROWCOLSCALE = 5, EPI_SWIGLU_BWD = 6, EPI_SWIGLU_FWD = 7, EPI_ROPE = 8, EPI_SPLITK = 9, EPI_ROWCOLSCALE_F32 = 10 };
 
 struct GemmArgs {
   const bf16_t* A; const bf16_t* B; bf16_t* C;
@@ -353,6 +354,31 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const GemmArgs g) {
     }
     return;
   }
+  if constexpr (EPI == EPI_ROWCOLSCALE_F32) {
+    // torchao::int8_mm_dequant with fp32 scales (the op returns dtype = A_scale.dtype, subclasses/int8_mm.py:136,143): the fp32 value
+    // (acc * a_scale) * b_scale leaves unrounded, 16 B per lane (4 consecutive columns of one row)
+    static_assert(I8, "int8 kernel only");
+    float* Cf = reinterpret_cast<float*>(g.C);
+    const float* saf = reinterpret_cast<const float*>(g.sa);
+    const float* sbf = reinterpret_cast<const float*>(g.sb);
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      const int gm = m0 + wm * WR + mi * 16 + frow;
+      const float rs = saf[min(gm, g.M - 1)];
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) {
+        const int gn = n0 + wn * 64 + ni * 16 + fq * 4;
+        if (gm < g.M && gn < g.col_end) {
+          const f32x4_t cs = *reinterpret_cast<const f32x4_t*>(sbf + gn);
+          f32x4_t c;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) c[e] = ((float)acc[mi][ni][e] * rs) * cs[e];
+          *reinterpret_cast<f32x4_t*>(Cf + (int64_t)gm * g.ldc + gn) = c;
+        }
+      }
+    }
+    return;
+  }
   // ---- epilogue: acc (C^T fragments: lane owns n = fq*4..+4 for m = frow) -> bf16 -> LDS tile -> coalesced rows.
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
@@ -495,14 +521,13 @@ static int gemm_pipe_mode() {
 template <int EPI, bool I8, int PIPE, int BNT = 256>
 static int launch_gemm_p(const GemmArgs& a, hipStream_t stream) {
   auto kern = gemm_nt_kernel<EPI, I8, PIPE, BNT>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
-    if (e != hipSuccess) {
-      llx_set_error("llx_gemm_nt_bf16: cannot raise dynamic LDS limit: %s", hipGetErrorString(e));
-      return LLX_ERR_LAUNCH;
-    }
-    attr_set = true;
+  // forward and autograd's backward thread may both be the first caller: the attribute is set exactly once, race-free
+  static std::once_flag attr_once;
+  static hipError_t attr_err = hipSuccess;
+  std::call_once(attr_once, [&] { attr_err = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES); });
+  if (attr_err != hipSuccess) {
+    llx_set_error("llx_gemm_nt_bf16: cannot raise dynamic LDS limit: %s", hipGetErrorString(attr_err));
+    return LLX_ERR_LAUNCH;
   }
   hipLaunchKernelGGL(kern, dim3(a.grid_m * a.grid_n * (EPI == EPI_SPLITK ? a.splits : 1)), dim3(512), GEMM_LDS_BYTES, stream, a);
   LLX_LAUNCH_CHECK("llx_gemm_nt_bf16");
@@ -696,6 +721,8 @@ extern "C" int llx_int8_mm_dequant(const void* A, int64_t lda, const void* B, in
   LLX_REQUIRE(N % 8 == 0 && ldc % 8 == 0, "llx_int8_mm_dequant: N and ldc must be multiples of 8");
   LLX_REQUIRE(lda % 16 == 0 && ldb % 16 == 0, "llx_int8_mm_dequant: int8 row strides must be multiples of 16");
   LLX_REQUIRE(((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) % 16 == 0, "llx_int8_mm_dequant: pointers must be 16-byte aligned");
+  LLX_REQUIRE(M < (1 << 30) && N < (1 << 30) && K < (1 << 30), "%s: dimension too large", "llx_int8_mm_dequant");
+  LLX_REQUIRE(M * lda < (int64_t)4294967296 && N * ldb < (int64_t)4294967296, "%s: operand larger than 4 GiB (32-bit tile offsets)", "llx_int8_mm_dequant");
   GemmArgs a;
   a.A = (const bf16_t*)A; a.B = (const bf16_t*)B; a.C = (bf16_t*)C; a.A2 = nullptr; a.B2 = nullptr;
   a.E = nullptr; a.E2 = nullptr; a.sa = (const bf16_t*)a_scale; a.sb = (const bf16_t*)b_scale;
@@ -707,6 +734,31 @@ extern "C" int llx_int8_mm_dequant(const void* A, int64_t lda, const void* B, in
   a.m_valid = nullptr;
   a.C32 = nullptr; a.splits = 1;
   return launch_gemm<EPI_ROWCOLSCALE, true>(a, stream);
+}
+
+// torchao::int8_mm_dequant with fp32 scales and an fp32 result (the reference returns dtype = A_scale.dtype for any float scale,
+// subclasses/int8_mm.py:126,136,143; train_librispeech.py:166-170 does not cast the model to bf16).  ldc in fp32 elements.
+extern "C" int llx_int8_mm_dequant_f32(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int64_t N,
+                                       int64_t K, const float* a_scale, const float* b_scale, hipStream_t stream) {
+  LLX_REQUIRE(A && B && C && a_scale && b_scale, "llx_int8_mm_dequant_f32: null pointer");
+  LLX_REQUIRE(M > 0 && N > 0 && K > 0, "llx_int8_mm_dequant_f32: empty problem");
+  LLX_REQUIRE(K % 128 == 0, "llx_int8_mm_dequant_f32: K=%lld must be a multiple of 128", (long long)K);
+  LLX_REQUIRE(N % 8 == 0 && ldc % 4 == 0, "llx_int8_mm_dequant_f32: N must be a multiple of 8 and ldc of 4");
+  LLX_REQUIRE(lda % 16 == 0 && ldb % 16 == 0, "llx_int8_mm_dequant_f32: int8 row strides must be multiples of 16");
+  LLX_REQUIRE(((uintptr_t)A | (uintptr_t)B | (uintptr_t)C | (uintptr_t)b_scale) % 16 == 0 && (uintptr_t)a_scale % 4 == 0, "llx_int8_mm_dequant_f32: unaligned pointer");
+  LLX_REQUIRE(M < (1 << 30) && N < (1 << 30) && K < (1 << 30), "%s: dimension too large", "llx_int8_mm_dequant_f32");
+  LLX_REQUIRE(M * lda < (int64_t)4294967296 && N * ldb < (int64_t)4294967296, "%s: operand larger than 4 GiB (32-bit tile offsets)", "llx_int8_mm_dequant_f32");
+  GemmArgs a;
+  a.A = (const bf16_t*)A; a.B = (const bf16_t*)B; a.C = (bf16_t*)C; a.A2 = nullptr; a.B2 = nullptr;
+  a.E = nullptr; a.E2 = nullptr; a.sa = (const bf16_t*)a_scale; a.sb = (const bf16_t*)b_scale;
+  a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.lde = 0; a.lda2 = 0; a.ldb2 = 0;
+  a.M = (int)M; a.N = (int)N; a.K = (int)K; a.K2 = 0;
+  a.grid_m = (int)cdiv64(M, BM); a.grid_n = (int)cdiv64(N, BN);
+  a.col0 = 0; a.col_end = (int)N;
+  a.rope = nullptr; a.rope_S = 0; a.rope_cols = 0;
+  a.m_valid = nullptr;
+  a.C32 = nullptr; a.splits = 1;
+  return launch_gemm<EPI_ROWCOLSCALE_F32, true>(a, stream);
 }
 
 // torchao::int8_mm_dequant with the neighbours of its call sites fused in (an int8 base with dynamically quantised activations,
@@ -732,6 +784,8 @@ extern "C" int llx_int8_mm_dequant_ext(const void* A, int64_t lda, const void* B
               "llx_int8_mm_dequant_ext: bad RoPE arguments");
   LLX_REQUIRE(epilogue != EPI_SWIGLU_FWD || N % 256 == 0, "llx_int8_mm_dequant_ext: the SwiGLU epilogue needs N = 2I with I a multiple of 128");
   LLX_REQUIRE(K2 == 0 || gemm_pipe_mode() == 1, "llx_int8_mm_dequant_ext: the K-extension needs the four-phase main loop (LLX_GEMM_PIPE unset or 1)");
+  LLX_REQUIRE(M < (1 << 30) && N < (1 << 30) && K < (1 << 30), "%s: dimension too large", "llx_int8_mm_dequant_ext");
+  LLX_REQUIRE(M * lda < (int64_t)4294967296 && N * ldb < (int64_t)4294967296, "%s: operand larger than 4 GiB (32-bit tile offsets)", "llx_int8_mm_dequant_ext");
   GemmArgs a;
   a.A = (const bf16_t*)A; a.B = (const bf16_t*)B; a.C = (bf16_t*)C; a.A2 = (const bf16_t*)A2; a.B2 = (const bf16_t*)B2;
   a.E = (const bf16_t*)E; a.E2 = nullptr; a.sa = (const bf16_t*)a_scale; a.sb = (const bf16_t*)b_scale;

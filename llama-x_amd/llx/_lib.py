@@ -26,9 +26,6 @@ SIGNATURES: dict[str, tuple] = {
     "llx_rmsnorm_fwd_quant": (c_int, [_P, _P, _P, _P, _P, _L, _P, _L, _L, _F, _P]),
     "llx_rmsnorm_bwd_workspace_bytes": (c_int64, [_L, _L]),
     "llx_rmsnorm_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _I, _P, _P, _L, _L, _P]),
-    "llx_debug_attn_fwd_occupancy": (c_int, []),
-    "llx_debug_attn_bwd_set_stamps": (c_int, [_P]),
-    "llx_debug_attn_fwd_stamps": (c_int, [_P, _P, _P, _P, _L, _L, _L, _P, _P]),
     "llx_attn_flags_bytes": (c_int64, [_L, _L]),
     "llx_attn_tile_flags": (c_int, [_P, _P, _P, _L, _L, _P]),
     "llx_attn_fwd": (c_int, [_P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _P, _P, _P, _L, _L, _L, _L, _L, _F, _P]),
@@ -47,6 +44,7 @@ SIGNATURES: dict[str, tuple] = {
     "llx_i8_to_bf16": (c_int, [_P, _P, _L, _P]),
     "llx_quantize_int8_rowwise": (c_int, [_P, _L, _P, _L, _P, _L, _L, _I, _P]),
     "llx_int8_mm_dequant": (c_int, [_P, _L, _P, _L, _P, _L, _L, _L, _L, _P, _P, _P]),
+    "llx_int8_mm_dequant_f32": (c_int, [_P, _L, _P, _L, _P, _L, _L, _L, _L, _P, _P, _P]),
     "llx_int8_mm_dequant_ext": (c_int, [_P, _L, _P, _L, _P, _L, _L, _L, _L, _P, _P, _P, _L, _P, _L, _L, _I, _P, _L, _P, _L, _L, _P]),
     "llx_mel_spectrogram": (c_int, [_P, _L, _L, _P, _P, _P, _P, _L, _L, _L, _P]),
     "llx_logmel_cmn": (c_int, [_P, _P, _L, _L, _L, _P]),
@@ -85,6 +83,13 @@ SIGNATURES: dict[str, tuple] = {
     "llx_gemm_nt_bf16_rope": (c_int, [_P, _L, _P, _L, _P, _L, _L, _L, _L, _P, _L, _P, _L, _L, _P, _L, _L, _P]),
 }
 
+# include/llx_debug.h: diagnostic probes, bound for tools/ only
+DEBUG_SIGNATURES: dict[str, tuple] = {
+    "llx_debug_attn_fwd_occupancy": (c_int, []),
+    "llx_debug_attn_bwd_set_stamps": (c_int, [_P]),
+    "llx_debug_attn_fwd_stamps": (c_int, [_P, _P, _P, _P, _L, _L, _L, _P, _P]),
+}
+
 
 class LlxError(RuntimeError):
     pass
@@ -101,7 +106,7 @@ def load():
             "(or `make -C llama-x_amd/csrc`). There is no fallback path."
         )
     lib = ctypes.CDLL(LIB_PATH)
-    for name, (res, args) in SIGNATURES.items():
+    for name, (res, args) in {**SIGNATURES, **DEBUG_SIGNATURES}.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args

@@ -3,6 +3,12 @@
 Same schema, assertions and Meta behaviour as the reference's Triton op (/root/reference/subclasses/int8_mm.py:121-149);
 the device implementation is the i8-MFMA GEMM of llama-x_amd/csrc/gemm_bf16.hip (v_mfma_i32_16x16x64_i8, int32
 accumulate, fp32 row*col scale epilogue, one rounding to the scale dtype).  As in the reference there is no CPU kernel.
+
+Scale dtypes: bf16 (the training path: llx_int8_mm_dequant), fp32 (llx_int8_mm_dequant_f32: the fp32 product leaves unrounded)
+and fp16 (the fp32 kernel on the exactly widened scales, then the ONE rounding to fp16 the reference's store makes) - the
+reference returns ``dtype=A_scale.dtype`` for any float scale (int8_mm.py:126,136,143).  Shapes the MFMA tiling does not take
+as they are (K not a multiple of 128, N not a multiple of 8, unaligned rows) are zero-padded on the way in: zero int8 products
+change no integer sum, padded output columns are sliced off - the result is bit-identical to the unpadded definition.
 """
 import torch
 from torch import Tensor
@@ -55,7 +61,7 @@ def _launch_impl(A: Tensor, Bt: Tensor, a_scale: Tensor, b_scale: Tensor, out: T
     M, Kd = A.shape
     N = Bt.shape[0]
     if a_scale.dtype is not torch.bfloat16:
-        raise L.LlxError(f"int8_mm_dequant: scales must be bf16 on the HIP path (got {a_scale.dtype})")
+        raise L.LlxError(f"int8 GEMM with fused neighbours: scales must be bf16 (got {a_scale.dtype})")
     if out is None:
         out = torch.empty(M, N, device=A.device, dtype=torch.bfloat16)
     if a2 is None and epilogue == 0 and rope is None:
@@ -88,11 +94,43 @@ def _launch_impl(A: Tensor, Bt: Tensor, a_scale: Tensor, b_scale: Tensor, out: T
     return out
 
 
+def _launch_f32(A: Tensor, Bt: Tensor, a_scale: Tensor, b_scale: Tensor) -> Tensor:
+    """fp32 scales -> fp32 product (no rounding after the two fp32 multiplies of subclasses/int8_mm.py:112-114)."""
+    M, Kd = A.shape
+    N = Bt.shape[0]
+    out = torch.empty(M, N, device=A.device, dtype=torch.float32)
+    L.check(L.load().llx_int8_mm_dequant_f32(L.ptr(A), A.stride(0), L.ptr(Bt), Bt.stride(0), L.ptr(out), out.stride(0), M, N, Kd,
+                                             L.ptr(a_scale), L.ptr(b_scale), L.stream()), "llx_int8_mm_dequant_f32")
+    return out
+
+
+def _rows_for_kernel(X: Tensor, k_pad: int, row_pad: int = 0) -> Tensor:
+    """int8 [R, K] rows with unit column stride, 16-byte aligned rows and base, K (and optionally R) zero-padded."""
+    if k_pad or row_pad:
+        return torch.nn.functional.pad(X, (0, k_pad, 0, row_pad))
+    if X.stride(1) != 1 or X.stride(0) % 16 != 0 or X.data_ptr() % 16 != 0:
+        return X.contiguous()
+    return X
+
+
 @torch.library.impl(_lib, "int8_mm_dequant", "CUDA")  # "CUDA" is the HIP dispatch key on PyTorch-ROCm
 def _hip(A, B, A_scale_rowwise, B_scale_colwise):
-    A = A if A.stride(1) == 1 else A.contiguous()
+    dtype = A_scale_rowwise.dtype
+    if dtype not in (torch.bfloat16, torch.float32, torch.float16):
+        raise L.LlxError(f"int8_mm_dequant: scale dtype {dtype} unsupported (bf16 / fp32 / fp16)")
+    M, Kd = A.shape
+    N = B.shape[1]
+    k_pad, n_pad = -Kd % 128, -N % 8
+    A = _rows_for_kernel(A, k_pad)
     # the kernel wants B's columns K-contiguous: B = W.T with strides (1, K) (reference call site subclasses/int8.py:113)
-    Bt = B.t()
-    if Bt.stride(1) != 1:
-        Bt = Bt.contiguous()
-    return _launch(A, Bt, A_scale_rowwise.reshape(-1), B_scale_colwise.reshape(-1))
+    Bt = _rows_for_kernel(B.t(), k_pad, n_pad)
+    sa, sb = A_scale_rowwise.reshape(-1), B_scale_colwise.reshape(-1)
+    if n_pad:
+        sb = torch.nn.functional.pad(sb, (0, n_pad))
+    if dtype is torch.bfloat16:
+        out = _launch(A, Bt, sa, sb)
+    else:
+        out = _launch_f32(A, Bt, sa.float(), sb.float().contiguous())
+        if dtype is torch.float16:
+            out = out.half()
+    return out[:, :N] if n_pad else out

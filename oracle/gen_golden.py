@@ -325,16 +325,8 @@ dst.copy_(wq)
 assert torch.equal(dst, wq.dequantize())
 save("g09_int8_linear", y=yi, dx=xi.grad, dequant_slice=wq.dequantize()[::8, ::8])
 
-# ------------------------------------------------------------------------------------------------- G10 int8_mm_dequant
-# The reference op has only Meta + CUDA (Triton) implementations (subclasses/int8_mm.py:135,140): not runnable on CPU.
-# The oracle restates the kernel text (:93-118); integer accumulation is order independent, so this IS the bit-exact target.
-a8 = O.randint("mm_a", (70, 256), -127, 128).to(torch.int8)
-b8 = O.randint("mm_b", (96, 256), -127, 128).to(torch.int8)
-sa = O.uniform("mm_sa", (70,), 0.001, 0.02).bfloat16()
-sb = O.uniform("mm_sb", (96,), 0.001, 0.02).bfloat16()
-meta = torch.ops.torchao.int8_mm_dequant(a8.to("meta"), b8.T.to("meta"), sa.to("meta"), sb.to("meta"))
-assert meta.shape == (70, 96) and meta.dtype is torch.bfloat16
-save("g10_int8_mm", c=O.int8_mm_dequant(a8, b8.T, sa, sb))
+# G10 (int8_mm_dequant) and G12 (the training scripts' iterators) are written by oracle/gen_golden_scripts.py, which EXECUTES the
+# reference's Triton kernel under TRITON_INTERPRET=1 and imports the scripts behind stand-in modules.
 
 # ------------------------------------------------------------------------------------------------- G11 audio path given mel
 pa = O.init_params(CFG, audio=True)

@@ -6,8 +6,8 @@ import re
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared():
-    text = open(os.path.join(ROOT, "include", "llx.h")).read()
+def _declared(header="llx.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(llx_[a-z0-9_]+)\s*\(", text)))
 
@@ -23,7 +23,14 @@ def test_header_and_library_agree():
         assert name in L.SIGNATURES, f"{name} has no ctypes signature in llx/_lib.py"
     for name in L.SIGNATURES:
         assert name in declared, f"{name} bound in llx/_lib.py but missing from include/llx.h"
-    assert lib.llx_version() == 101
+    debug = _declared("llx_debug.h")  # diagnostic probes live in their own header, outside the boundary
+    assert debug and not set(debug) & set(declared) and all(n.startswith("llx_debug_") for n in debug)
+    assert not any(n.startswith("llx_debug_") for n in declared)
+    for name in debug:
+        assert hasattr(lib, name) and name in L.DEBUG_SIGNATURES, name
+    assert sorted(L.DEBUG_SIGNATURES) == debug
+    assert sorted(f for f in os.listdir(os.path.join(ROOT, "include")) if f.endswith(".h")) == ["llx.h", "llx_debug.h"]
+    assert lib.llx_version() == 102
     assert isinstance(lib.llx_last_error_string(), (bytes, type(None)))
 
 

@@ -137,6 +137,68 @@ def test_lr_schedule():
     assert f(0) == 0.0 and f(5) == 0.5 and f(10) == 1.0 and f(79) == 1.0 and f(80) == 1.0 and f(90) == 0.5 and f(100) == 1.0
 
 
+# ---------------------------------------------------------------------------------------------- G12: product vs the reference's own batches
+def _g12(name):
+    import os
+
+    import numpy as np
+
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".npz"))
+
+
+def test_product_iterators_reproduce_reference_fixtures(tmp_path):
+    """llx.data against tests/golden/g12_* = what the reference's train_metamathqa.py / train_librispeech.py / train_utils.py
+    produced on the same seeded inputs (oracle/gen_golden_scripts.py): M1, M2 (+ mask bits through MaskSpec's rule), M4, the
+    utterance packer incl. the transcript listing, and the LR schedule.  Bit-exact."""
+    import numpy as np
+
+    from llx import data as D
+    from oracle import script_cases as SC
+
+    docs = SC.documents()
+    g = _g12("g12_padding")
+    torch.manual_seed(SC.PAD_SEED)
+    it = D.padding_iterator(list(docs), SC.PAD_BATCH, SC.PAD_MULTIPLE)
+    for i in range(SC.PAD_N):
+        inputs, labels, mask = next(it)
+        assert mask is None and np.array_equal(inputs.numpy(), g[f"inputs_{i}"]) and np.array_equal(labels.numpy(), g[f"labels_{i}"])
+    g = _g12("g12_document_mask")
+    torch.manual_seed(SC.PACK_SEED)
+    it = D.document_mask_iterator(list(docs), SC.PACK_SEQ)
+    for i in range(SC.PACK_N):
+        inputs, labels, spec = next(it)
+        assert inputs.shape == (1, SC.PACK_SEQ) and np.array_equal(inputs.numpy(), g[f"inputs_{i}"]) and np.array_equal(labels.numpy(), g[f"labels_{i}"])
+        assert spec.prefix_len is None and np.array_equal(spec.doc_ids.numpy(), g[f"doc_ids_{i}"])
+        # the rule the attention kernels apply to a MaskSpec(doc_ids): same document AND q >= kv
+        ids = spec.doc_ids
+        idx = torch.arange(SC.PACK_SEQ)
+        dense = (ids[:, None] == ids[None, :]) & (idx[:, None] >= idx[None, :])
+        assert np.array_equal(np.packbits(dense.numpy(), axis=1), g[f"mask_bits_{i}"])
+    g = _g12("g12_librispeech")
+    tok = SC.ToyTokenizer()
+    SC.write_transcripts(tmp_path)
+    samples = D.librispeech_samples(tmp_path, tok)
+    assert [p for p, _ in samples] == g["listing_paths"].tolist() and [len(t) for _, t in samples] == g["listing_tokens"].tolist()
+    a, t, lab = D.prepare_audio_batch(SC.prepare_batch_case(), int(SC.AUDIO_SECONDS * SC.AUDIO_RATE), SC.AUDIO_MULTIPLE, tok.pad_id)
+    assert np.array_equal(a.numpy(), g["prep_audio"]) and np.array_equal(t.numpy(), g["prep_tokens"]) and np.array_equal(lab.numpy(), g["prep_labels"])
+    import os
+
+    clips = SC.clips()
+    torch.manual_seed(SC.AUDIO_SEED)
+    it = iter(D.UtterancePacker(samples, lambda p: clips[os.path.basename(str(p))], audio_duration=SC.AUDIO_SECONDS, seq_len_multiple=SC.AUDIO_MULTIPLE,
+                                batch_size=SC.AUDIO_BATCH, bos_id=tok.bos_id, eos_id=tok.eos_id, pad_id=tok.pad_id, sample_rate=SC.AUDIO_RATE))
+    for i in range(SC.AUDIO_N):
+        for nm, v in zip(("audio", "tokens", "labels"), next(it)):
+            assert np.array_equal(v.numpy(), g[f"{nm}_{i}"]), (i, nm)
+    g = _g12("g12_lr_schedule")
+    for i, (lr, n, wu, dc) in enumerate(SC.LR_CASES):
+        sch = D.LRScheduler(lr, n, wu, dc)
+        assert [sch.get_lr(s) for s in range(n + 3)] == g[f"case_{i}"].tolist()
+        opt = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=torch.tensor(0.5))
+        sch.set_lr(opt, n // 2)
+        assert isinstance(opt.param_groups[0]["lr"], torch.Tensor) and float(opt.param_groups[0]["lr"]) == np.float32(g[f"case_{i}"][n // 2])
+
+
 # ---------------------------------------------------------------------------------------------- product API surface
 def test_module_api_and_state_dict_names():
     from modelling import AudioConfig, DoRALinear, Llama, LlamaAudio, LlamaConfig, LoRALinear, apply_linear_adapter_

@@ -583,21 +583,33 @@ def test_int8_mm_dequant_registered_op_with_transposed_view(cuda):
     implementation, bit-exact against the golden vector g10_int8_mm; also a contiguous [K, N] B and the python wrapper's asserts."""
     from subclasses.int8_mm import int8_mm_dequant
 
-    g = _gold("g10_int8_mm")
-    a8 = O.randint("mm_a", (70, 256), -127, 128).to(torch.int8).to(cuda)
-    b8 = O.randint("mm_b", (96, 256), -127, 128).to(torch.int8).to(cuda)
-    sa = O.uniform("mm_sa", (70,), 0.001, 0.02).bfloat16().to(cuda)
-    sb = O.uniform("mm_sb", (96,), 0.001, 0.02).bfloat16().to(cuda)
-    Bv = b8.T
-    assert Bv.stride() == (1, 256) and not Bv.is_contiguous()
+    from oracle import script_cases as SC
+
+    g = _gold("g10_int8_mm")  # outputs of the reference's Triton kernel, executed under TRITON_INTERPRET (oracle/gen_golden_scripts.py)
+    for name, (M, N, K, _blocks) in SC.INT8_MM_CASES.items():
+        a8, w8, sa, sb = (t.to(cuda) for t in SC.int8_mm_inputs(name, M, N, K))
+        Bv = w8.T
+        assert Bv.stride() == (1, K) and not Bv.is_contiguous()
+        c = torch.ops.torchao.int8_mm_dequant(a8, Bv, sa.bfloat16(), sb.bfloat16())
+        assert c.shape == (M, N) and c.dtype is torch.bfloat16 and c.is_cuda
+        assert torch.equal(c.cpu().float(), g[f"{name}_c_bf16"]), f"registered op differs from the reference kernel's output [{name}]"
+        # fp32 scales -> fp32 result (dtype = A_scale.dtype, subclasses/int8_mm.py:136,143); fp16: one rounding of the same fp32 value
+        c32 = torch.ops.torchao.int8_mm_dequant(a8, Bv, sa, sb)
+        assert c32.dtype is torch.float32 and torch.equal(c32.cpu(), g[f"{name}_c_f32"]), f"fp32 scales [{name}]"
+        c16 = torch.ops.torchao.int8_mm_dequant(a8, Bv, sa.half(), sb.half())
+        assert c16.dtype is torch.float16 and torch.equal(c16.cpu(), O.int8_mm_dequant(a8.cpu(), Bv.cpu(), sa.half().cpu(), sb.half().cpu()))
+    M, N, K, _ = SC.INT8_MM_CASES["ragged"]
+    a8, w8, sa, sb = (t.to(cuda) for t in SC.int8_mm_inputs("ragged", M, N, K))
+    sa, sb, Bv = sa.bfloat16(), sb.bfloat16(), w8.T
     c = torch.ops.torchao.int8_mm_dequant(a8, Bv, sa, sb)
-    assert c.shape == (70, 96) and c.dtype is torch.bfloat16 and c.is_cuda
-    assert torch.equal(c.cpu().float(), g["c"]), "registered op differs from the golden vector"
     assert torch.equal(int8_mm_dequant(a8, Bv, sa, sb), c)                       # python wrapper (asserts of int8_mm.py:124-132)
     assert torch.equal(int8_mm_dequant(a8, Bv.contiguous(), sa, sb), c)          # a row-major [K, N] B is re-laid out
-    assert torch.equal(int8_mm_dequant(a8, Bv, sa.view(70, 1), sb.view(1, 96)), c)  # keepdim scales (.squeeze() in the asserts)
+    assert torch.equal(int8_mm_dequant(a8, Bv, sa.view(M, 1), sb.view(1, N)), c)  # keepdim scales (.squeeze() in the asserts)
     with pytest.raises(AssertionError):
         int8_mm_dequant(a8, Bv, sa.float(), sb)
+    # K not a multiple of 128 and unaligned rows: zero padding on the way in, identical integers
+    a_odd, w_odd = a8[:, :200].contiguous(), w8[:, :200].contiguous()
+    assert torch.equal(int8_mm_dequant(a_odd, w_odd.T, sa, sb).cpu(), O.int8_mm_dequant(a_odd.cpu(), w_odd.T.cpu(), sa.cpu(), sb.cpu()))
     # a production shape: activations [4096, 4096] x W[1024, 4096].T, against the oracle's integer restatement
     A = O.randint("mm_A", (4096, 4096), -127, 128).to(torch.int8)
     W = O.randint("mm_W", (1024, 4096), -127, 128).to(torch.int8)

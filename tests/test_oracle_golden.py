@@ -9,6 +9,7 @@ import pytest
 import torch
 
 from oracle import ref as O
+from oracle import script_cases as SC
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 CFG = O.TINY
@@ -156,12 +157,57 @@ def test_int8_bit_exact():
     y.backward(O.randn("i8_g", (40, 256)).bfloat16())
     assert torch.equal(y.float(), gl["y"]) and torch.equal(x.grad.float(), gl["dx"])
     assert torch.equal(O.int8_dequantize(wq, ws)[::8, ::8].float(), gl["dequant_slice"])
+
+
+def test_int8_mm_dequant_against_the_executed_reference_kernel():
+    """A23: g10 holds what the reference's Triton kernel (subclasses/int8_mm.py:50-118) computed under TRITON_INTERPRET=1
+    (oracle/gen_golden_scripts.py): fp32 output with fp32 scales, and the bf16 result for bf16 scales; B is the non-contiguous
+    W.T view of subclasses/int8.py:113; M / N not multiples of the block sizes."""
     gm = G("g10_int8_mm")
-    a8 = O.randint("mm_a", (70, 256), -127, 128).to(torch.int8)
-    b8 = O.randint("mm_b", (96, 256), -127, 128).to(torch.int8)
-    sa, sb = O.uniform("mm_sa", (70,), 0.001, 0.02).bfloat16(), O.uniform("mm_sb", (96,), 0.001, 0.02).bfloat16()
-    assert torch.equal(O.int8_mm_dequant(a8, b8.T, sa, sb).float(), gm["c"])  # also through a non-contiguous B view
-    assert torch.equal(O.int8_mm_dequant(a8, b8.T.contiguous(), sa, sb).float(), gm["c"])
+    for name, (M, N, K, _blocks) in SC.INT8_MM_CASES.items():
+        a8, w8, sa, sb = SC.int8_mm_inputs(name, M, N, K)
+        c32 = O.int8_mm_dequant(a8, w8.T, sa, sb)
+        assert c32.dtype is torch.float32 and torch.equal(c32, gm[f"{name}_c_f32"])
+        cb = O.int8_mm_dequant(a8, w8.T, sa.bfloat16(), sb.bfloat16())
+        assert cb.dtype is torch.bfloat16 and torch.equal(cb.float(), gm[f"{name}_c_bf16"])
+        assert torch.equal(O.int8_mm_dequant(a8, w8.T.contiguous(), sa, sb), c32)
+
+
+# ------------------------------------------------------------------------------------------------- G12: the training scripts' iterators
+def test_padding_iterator_matches_reference_batches():
+    g = G("g12_padding")
+    torch.manual_seed(SC.PAD_SEED)
+    for i, (inputs, labels) in enumerate(SC.oracle_padding_batches(SC.documents())):
+        assert inputs.dtype is torch.int64 and torch.equal(inputs, g[f"inputs_{i}"]) and torch.equal(labels, g[f"labels_{i}"])
+
+
+def test_document_packer_matches_reference_buffers_and_mask_bits():
+    g = G("g12_document_mask")
+    torch.manual_seed(SC.PACK_SEED)
+    for i, (inputs, labels, doc_ids) in enumerate(SC.oracle_packed_buffers(SC.documents())):
+        assert torch.equal(inputs.view(1, -1), g[f"inputs_{i}"]) and torch.equal(labels.view(1, -1), g[f"labels_{i}"])
+        assert torch.equal(doc_ids, g[f"doc_ids_{i}"])
+        bits = torch.from_numpy(np.packbits(O.document_mask(doc_ids).numpy(), axis=1))
+        assert torch.equal(bits, g[f"mask_bits_{i}"]), "dense mask of the reference's mask_mod closure (train_metamathqa.py:67-68)"
+
+
+def test_librispeech_batches_match_reference():
+    g = np.load(os.path.join(GOLD, "g12_librispeech.npz"))
+    tok = SC.ToyTokenizer()
+    listing = O.list_transcripts(SC.TRANSCRIPTS, tok)
+    assert [p for p, _ in listing] == g["listing_paths"].tolist() and [len(t) for _, t in listing] == g["listing_tokens"].tolist()
+    a, t, lab = O.prepare_audio_batch(SC.prepare_batch_case(), int(SC.AUDIO_SECONDS * SC.AUDIO_RATE), SC.AUDIO_MULTIPLE, tok.pad_id)
+    assert np.array_equal(a.numpy(), g["prep_audio"]) and np.array_equal(t.numpy(), g["prep_tokens"]) and np.array_equal(lab.numpy(), g["prep_labels"])
+    torch.manual_seed(SC.AUDIO_SEED)
+    for i, batch in enumerate(SC.oracle_utterance_batches(listing, SC.clips())):
+        for nm, v in zip(("audio", "tokens", "labels"), batch):
+            assert np.array_equal(v.numpy(), g[f"{nm}_{i}"]), (i, nm)
+
+
+def test_lr_schedule_matches_reference():
+    g = G("g12_lr_schedule")
+    for i, (lr, n, wu, dc) in enumerate(SC.LR_CASES):
+        assert [O.lr_at(s, lr, n, wu, dc) for s in range(n + 3)] == g[f"case_{i}"].tolist()
 
 
 def test_audio_path_given_mel():
