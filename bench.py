@@ -240,8 +240,20 @@ def run_workload(args, config: str, device, world: int, rank: int, steps: int, w
         step = eager_step
         launch_mode = "eager, 4 backward stages, RCCL all-reduce of stage k under the backward of stage k-1"
         if use_graph:
+            captured = True
             try:
                 stepper.capture(ids_buf)
+            except Exception as exc:  # noqa: BLE001 - a capture problem must not cost the measurement: the same stages run eagerly
+                captured = False
+                print(f"[bench] rank {rank}: stage capture failed ({type(exc).__name__}: {exc}); running the stages eagerly", file=sys.stderr, flush=True)
+                torch.cuda.synchronize()
+            if world > 1:
+                # graph or eager is decided by ALL ranks together: a rank replaying graphs next to one launching eagerly would still
+                # exchange the same buckets, but the choice must not depend on which rank hit the problem
+                flag = torch.tensor([1 if captured else 0], device=device, dtype=torch.int32)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                captured = bool(flag.item())
+            if captured:
 
                 def step():
                     ids, labels = batch()
@@ -250,9 +262,7 @@ def run_workload(args, config: str, device, world: int, rank: int, steps: int, w
                     return stepper(ids_buf)
 
                 launch_mode = "hipGraph replay per stage (fwd | 4 x bwd | AdamW), RCCL all-reduce of stage k under the backward of stage k-1"
-            except Exception as exc:  # noqa: BLE001 - a capture problem must not cost the measurement: the same stages run eagerly
-                print(f"[bench] rank {rank}: stage capture failed ({type(exc).__name__}: {exc}); running the stages eagerly", file=sys.stderr, flush=True)
-                torch.cuda.synchronize()
+            else:
                 stepper._graphs = None
                 step = eager_step
     else:

@@ -20,17 +20,30 @@ Dense trainable weights (embeddings, LM head, conv kernels: ndim >= 2 and not an
 enough to fill the chip on their own, and the host-side weight images (transposed / concatenated copies, llx.ops._cached) are keyed on
 their version counters, which an update through a flat alias would not bump.
 
-Accumulation micro-steps and anything that does not write in place stay correct: a gradient that finds ``param.grad`` already set is
-produced in a fresh buffer and added by autograd (into the arena view), and ``settle()`` repairs whatever ended up elsewhere (copies a
-foreign ``.grad`` into its slot, zeroes the slot of a parameter that got no gradient) before the exchange / optimizer read G.
+Accumulation micro-steps and anything that does not write in place stay correct: a gradient that finds ``param.grad`` already set (or
+whose slot another autograd node of the same backward has already claimed: a shared norm / adapter) is produced in a fresh buffer and
+added by autograd, and ``settle()`` repairs whatever ended up elsewhere (copies a foreign ``.grad`` into its slot, zeroes the slot of a
+parameter that got no gradient) before the exchange / optimizer read G.
+
+The arena is self-contained for the reference's plain loop ``loss.backward(); optim.step(); optim.zero_grad()``
+(train_metamathqa.py:253-254, train_librispeech.py:243-244): it registers optimizer step hooks that fire for any optimizer built on
+``arena.params()``.  Before the step the flat gradient is re-attached (``zero_grad(set_to_none=True)`` drops it), ``settle()`` runs, and
+members WITHOUT a gradient this step are put aside; after the step their parameter values are restored (the per-tensor optimizer of the
+reference skips such parameters entirely - no weight decay, no moment decay; with zero moments the flat update is exactly the decay
+term, which the restore undoes) and every member's ``.grad`` view is dropped so that the next backward writes G in place again instead of
+accumulating.  One stated difference remains: the flat optimizer has ONE step counter, so a member that sits idle for some steps and then
+receives gradients sees the bias correction of the global step, not of its own count.
 Build the arena LAST - after adapters are applied, the base is quantised, requires_grad flags are final and the model sits on its device
 (``model.to(...)`` re-creates parameter storage and would cut the views; ``load_state_dict`` copies in place and is fine).  ``verify()``
 checks that every trainable parameter is still covered and still aliases the arena.
-The checkpoint wire format keeps the reference's per-parameter optimizer state (train_metamathqa.py:259-265): ``optim_state_dict`` /
-``load_optim_state_dict`` translate.
+The checkpoint wire format keeps the reference's per-parameter optimizer state (train_metamathqa.py:259-265), numbered as the
+reference numbers it: its optimizer is built on ``model.parameters()`` (train_metamathqa.py:188, train_librispeech.py:181), frozen
+parameters included - they take an index and simply have no state entry.  ``optim_state_dict`` / ``load_optim_state_dict`` translate
+(shapes checked entry by entry).
 """
 from __future__ import annotations
 
+import weakref
 from typing import Iterable, Optional
 
 import torch
@@ -71,8 +84,8 @@ def _layer_order(layer: nn.Module) -> list[nn.Parameter]:
 
 class TrainableArena:
     def __init__(self, model: nn.Module):
+        self.model_order = list(model.parameters())  # = the parameter numbering of optim_cls(model.parameters()) (checkpoint wire format)
         named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
-        self.model_order = [p for _, p in named]  # = the parameter numbering of torch.optim.X(trainables) (checkpoint wire format)
         small = {id(p) for n, p in named if _is_small(n, p)}
         layer_of: dict[int, nn.Module] = {}
         for layer in getattr(model, "layers", []):
@@ -91,6 +104,8 @@ class TrainableArena:
         self.members = ordered
         self.dense = [p for _, p in named if id(p) not in small]
         self.flat: list[nn.Parameter] = []  # one per (dtype, device)
+        self._G: list[Tensor] = []          # the gradient buffer of each flat parameter (flat.grad may be dropped by zero_grad)
+        self._idle: list[tuple[nn.Parameter, Tensor]] = []  # members without a gradient this step: (member, parameter values to restore)
         self._slot_of: dict[int, tuple[int, int, int]] = {}  # id(param) -> (flat index, offset, numel)
         by_key: dict = {}
         for p in ordered:
@@ -111,7 +126,54 @@ class TrainableArena:
             fp = nn.Parameter(P, requires_grad=True)
             fp.grad = G
             self.flat.append(fp)
+            self._G.append(G)
         model._llx_arena = self
+        self._install_step_hooks()
+
+    # ---- optimizer step hooks: what makes `loss.backward(); optim.step(); optim.zero_grad()` correct without further calls
+    def _owns(self, optim: torch.optim.Optimizer) -> bool:
+        return bool(self.flat) and any(p is self.flat[0] for g in optim.param_groups for p in g["params"])
+
+    def _install_step_hooks(self):
+        from torch.optim.optimizer import register_optimizer_step_post_hook, register_optimizer_step_pre_hook
+
+        ref = weakref.ref(self)
+        handles: list = []
+
+        def pre(optim, args, kwargs):
+            arena = ref()
+            if arena is not None and arena._owns(optim):
+                arena.before_step()
+
+        def post(optim, args, kwargs):
+            arena = ref()
+            if arena is not None and arena._owns(optim):
+                arena.after_step()
+
+        handles += [register_optimizer_step_pre_hook(pre), register_optimizer_step_post_hook(post)]
+        self._hook_handles = handles
+        weakref.finalize(self, lambda hs=handles: [h.remove() for h in hs])  # the global hooks go when the arena goes
+
+    def close(self):
+        """Remove the optimizer step hooks (the views stay)."""
+        for h in getattr(self, "_hook_handles", []):
+            h.remove()
+        self._hook_handles = []
+
+    def before_step(self):
+        for fp, G in zip(self.flat, self._G):
+            if fp.grad is not G:
+                fp.grad = G  # optim.zero_grad(set_to_none=True) dropped it: without this the optimizer would skip the whole arena
+        self._idle = [(p, p.detach().clone()) for p in self.members if p.grad is None]
+        self.settle()
+
+    def after_step(self):
+        with torch.no_grad():
+            for p, keep in self._idle:
+                p.copy_(keep)  # a member without a gradient is skipped by the reference's per-tensor optimizer
+        self._idle = []
+        for p in self.members:
+            p.grad = None  # the next backward writes its slot of G in place (a kept view would make autograd accumulate)
 
     # ---- what the optimizer is built on
     def params(self) -> list[nn.Parameter]:
@@ -147,7 +209,7 @@ class TrainableArena:
                 out[-1][2] = o + n
             else:
                 out.append([fi, o, o + n])
-        return [self.flat[fi].grad[lo:hi] for fi, lo, hi in out]
+        return [self._G[fi][lo:hi] for fi, lo, hi in out]
 
     def settle(self, params: Optional[Iterable[nn.Parameter]] = None):
         """Make G hold this step's gradient of every given member (default: all) before something reads G as a whole: a ``.grad`` that
@@ -156,6 +218,7 @@ class TrainableArena:
         for p in self.members if params is None else params:
             if id(p) not in self._slot_of:
                 continue
+            p._llx_claimed = False
             dst = self.grad_view(p)
             if p.grad is None:
                 dst.zero_()
@@ -167,10 +230,11 @@ class TrainableArena:
         """Drop the per-parameter views (the next backward writes G in place); G itself needs no memset."""
         for p in self.members:
             p.grad = None
+            p._llx_claimed = False
         for p in self.dense:
             p.grad = None
 
-    # ---- checkpoint wire format: per-parameter optimizer state, numbered as torch.optim.X(trainable parameters in model order)
+    # ---- checkpoint wire format: per-parameter optimizer state, numbered as optim_cls(model.parameters()) numbers it
     def optim_state_dict(self, optim: torch.optim.Optimizer) -> dict:
         sd = optim.state_dict()
         n_flat = len(self.flat)
@@ -194,6 +258,19 @@ class TrainableArena:
     def load_optim_state_dict(self, optim: torch.optim.Optimizer, sd: dict):
         index = {id(p): i for i, p in enumerate(self.model_order)}
         n_flat = len(self.flat)
+        listed = [i for g in sd["param_groups"] for i in g["params"]]
+        if len(listed) != len(self.model_order):
+            raise ValueError(f"optimizer checkpoint numbers {len(listed)} parameters, the model has {len(self.model_order)} "
+                             "(the reference builds its optimizer on model.parameters(), frozen ones included)")
+        for p in self.model_order:
+            st = sd["state"].get(index[id(p)])
+            if st is None:
+                continue
+            if not p.requires_grad:
+                raise ValueError(f"optimizer checkpoint holds state for parameter {index[id(p)]}, which is frozen in this model")
+            for k, v in st.items():
+                if torch.is_tensor(v) and v.dim() > 0 and tuple(v.shape) != tuple(p.shape):
+                    raise ValueError(f"optimizer checkpoint entry {index[id(p)]}[{k}] has shape {tuple(v.shape)}, the parameter {tuple(p.shape)}")
         state: dict = {}
         for fi, fp in enumerate(self.flat):
             mine = [p for p in self.members if self._slot_of[id(p)][0] == fi and index[id(p)] in sd["state"]]

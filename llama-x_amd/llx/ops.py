@@ -475,12 +475,14 @@ class GroupPlan:
 
 def _grad_dst(params: Sequence[Optional[Tensor]], shape: Optional[tuple] = None) -> Optional[Tensor]:
     """Where backward may write the gradients of `params` directly: the slice of the trainable arena's gradient buffer
-    (llx.arena.TrainableArena) that covers them back to back, or None - not in an arena, not adjacent in this order, or one of them
-    already has a ``.grad`` (accumulation micro-step: autograd has to ADD, so the product goes to a fresh buffer)."""
+    (llx.arena.TrainableArena) that covers them back to back, or None - not in an arena, not adjacent in this order, one of them
+    already has a ``.grad`` (accumulation micro-step: autograd has to ADD, so the product goes to a fresh buffer), or another autograd
+    node of this backward has already been given the slot (a parameter with two consumers: the second product must not overwrite the
+    first; the claim is released by the arena's settle() / zero_grad() / optimizer-step hook)."""
     g0 = first = end = None
     for p in params:
         slot = getattr(p, "_llx_slot", None)
-        if slot is None or p.grad is not None:
+        if slot is None or p.grad is not None or getattr(p, "_llx_claimed", False):
             return None
         G, off, n = slot
         if g0 is None:
@@ -490,6 +492,8 @@ def _grad_dst(params: Sequence[Optional[Tensor]], shape: Optional[tuple] = None)
         end = off + n
     if g0 is None:
         return None
+    for p in params:
+        p._llx_claimed = True
     out = g0[first:end]
     return out.view(shape) if shape is not None else out
 

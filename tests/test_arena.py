@@ -71,7 +71,7 @@ def test_flat_optimizer_matches_per_tensor_optimizer_and_checkpoint_format(tmp_p
     m = copy.deepcopy(ref)
     arena = TrainableArena(m)
     kw = dict(lr=1e-2, weight_decay=0.01, betas=(0.9, 0.95))
-    opt_ref = torch.optim.AdamW([p for p in ref.parameters() if p.requires_grad], **kw)
+    opt_ref = torch.optim.AdamW(ref.parameters(), **kw)  # as the reference scripts build it: frozen parameters included (train_metamathqa.py:188)
     opt = torch.optim.AdamW(arena.params(), **kw)
     tr = Trainer(m, opt, grad_accum=2, clip_grad_norm=0.5)
     for step in range(3):
@@ -83,17 +83,19 @@ def test_flat_optimizer_matches_per_tensor_optimizer_and_checkpoint_format(tmp_p
         opt_ref.zero_grad()
         tr.step([lambda mm, x=x: mm(x) for x in xs])
         for (n, p), (_, q) in zip(ref.named_parameters(), m.named_parameters()):
-            assert n == "unused" or torch.allclose(p, q, rtol=1e-6, atol=1e-7), (step, n)
-    # `unused` never had a gradient: the per-tensor optimizer skipped it; the arena zeroed its slot, and a zero gradient with zero
-    # moments moves nothing but the weight decay - which the reference optimizer did not apply.  That is the one stated difference:
-    assert torch.equal(ref.unused, torch.ones(7)) and torch.allclose(m.unused, torch.ones(7) * (1 - 1e-2 * 0.01) ** 3)
-    # checkpoint: per-parameter numbering of torch.optim.AdamW(trainables in model order)
+            assert torch.allclose(p, q, rtol=1e-6, atol=1e-7), (step, n)
+    # `unused` never had a gradient: the per-tensor optimizer skipped it (no weight decay either); the arena's step hooks put its
+    # values aside and restore them, so it does not drift
+    assert torch.equal(ref.unused, torch.ones(7)) and torch.equal(m.unused, torch.ones(7))
+    # checkpoint: per-parameter numbering of torch.optim.AdamW(model.parameters()) - the frozen `weight` takes index 0 and has no state
     sd, sd_ref = tr.state_dict()["optim"], opt_ref.state_dict()
-    assert sd["param_groups"][0]["params"] == sd_ref["param_groups"][0]["params"]
-    names = [n for n, p in ref.named_parameters() if p.requires_grad]
+    assert sd["param_groups"][0]["params"] == sd_ref["param_groups"][0]["params"] == list(range(7))
+    names = [n for n, p in ref.named_parameters()]
+    assert names[0] == "weight" and 0 not in sd["state"] and 0 not in sd_ref["state"]
+    assert sorted(k for k in sd["state"] if names[k] != "unused") == sorted(sd_ref["state"])
     for i, n in enumerate(names):
-        if n == "unused":
-            assert i not in sd_ref["state"]  # (the arena reports zero moments for it)
+        if n in ("unused", "weight"):
+            assert i not in sd_ref["state"]  # (the arena reports zero moments for `unused`)
             continue
         for k in ("exp_avg", "exp_avg_sq"):
             assert sd["state"][i][k].shape == sd_ref["state"][i][k].shape, (n, k)
@@ -114,6 +116,80 @@ def test_flat_optimizer_matches_per_tensor_optimizer_and_checkpoint_format(tmp_p
     tr2.step([lambda mm, x=x: mm(x) for x in xs])
     for (n, p), (_, q) in zip(m.named_parameters(), m2.named_parameters()):
         assert torch.equal(p, q), n
+    # a checkpoint written by the REFERENCE's optimizer (AdamW over model.parameters()) loads into the arena and continues identically
+    m3 = Toy()
+    m3.load_state_dict(ref.state_dict())
+    arena3 = TrainableArena(m3)
+    opt3 = torch.optim.AdamW(arena3.params(), **kw)
+    arena3.load_optim_state_dict(opt3, copy.deepcopy(opt_ref.state_dict()))
+    x = _data(20)
+    ref(x).backward()
+    opt_ref.step()
+    opt_ref.zero_grad()
+    m3(x).backward()
+    opt3.step()
+    opt3.zero_grad()
+    for (n, p), (_, q) in zip(ref.named_parameters(), m3.named_parameters()):
+        assert torch.allclose(p, q, rtol=1e-6, atol=1e-7), n
+    # ... and a checkpoint numbered over the trainables only (or with the wrong shapes) is refused instead of mis-assigned
+    bad = copy.deepcopy(opt_ref.state_dict())
+    bad["param_groups"][0]["params"] = list(range(6))
+    try:
+        arena3.load_optim_state_dict(opt3, bad)
+        raise AssertionError("a checkpoint with another parameter numbering must be refused")
+    except ValueError as e:
+        assert "numbers 6 parameters" in str(e)
+    bad = copy.deepcopy(opt_ref.state_dict())
+    bad["state"][1]["exp_avg"] = bad["state"][2]["exp_avg"]  # lora_a's moment replaced by lora_b's
+    try:
+        arena3.load_optim_state_dict(opt3, bad)
+        raise AssertionError("a mis-shaped state entry must be refused")
+    except ValueError as e:
+        assert "shape" in str(e)
+
+
+def test_plain_reference_loop_without_trainer():
+    """The reference's loop body (train_metamathqa.py:226-254): loss.backward(); [clip]; optim.step(); optim.zero_grad() - no Trainer, no
+    GradBuckets, no explicit settle(): the arena's optimizer step hooks keep it correct (zero_grad(set_to_none=True) drops the flat
+    gradient, CPU autograd produces gradients outside the arena, members' .grad must not accumulate across steps)."""
+    from llx.arena import TrainableArena
+
+    ref = Toy()
+    m = copy.deepcopy(ref)
+    kw = dict(lr=1e-2, weight_decay=0.05)
+    opt_ref = torch.optim.AdamW(ref.parameters(), **kw)
+    opt = torch.optim.AdamW(TrainableArena(m).params(), **kw)  # the one changed line
+    for step in range(4):
+        for mm, oo in ((ref, opt_ref), (m, opt)):
+            for micro in range(2):  # gradient accumulation as the scripts do it
+                (mm(_data(2 * step + micro)) / 2).backward()
+            torch.nn.utils.clip_grad_norm_(mm.parameters(), 0.7)
+            oo.step()
+            oo.zero_grad()
+        for (n, p), (_, q) in zip(ref.named_parameters(), m.named_parameters()):
+            assert torch.allclose(p, q, rtol=1e-6, atol=1e-7), (step, n)
+        assert all(p.grad is None for p in m.parameters())
+    assert torch.equal(m.unused, torch.ones(7))
+
+
+def test_grad_slot_is_claimed_once_per_backward():
+    """llx.ops._grad_dst hands a parameter's arena slot to ONE producer per backward: a second autograd node of the same backward (a
+    shared norm weight / adapter) gets None, writes a fresh buffer and autograd sums; the claim is released by settle()."""
+    from llx.arena import TrainableArena
+    from llx.ops import _grad_dst
+
+    m = Toy()
+    arena = TrainableArena(m)
+    first = _grad_dst([m.gain])
+    assert first is not None and first.data_ptr() == arena.grad_view(m.gain).data_ptr()
+    assert _grad_dst([m.gain]) is None, "second producer in the same backward must not get the same slice"
+    assert _grad_dst([m.lora_a, m.lora_b]) is None, "slots padded apart (64 of 128 elements used): not one contiguous slice"
+    assert _grad_dst([m.lora_b]) is not None and _grad_dst([m.lora_b]) is None
+    arena.settle()
+    assert _grad_dst([m.gain]) is not None
+    arena.zero_grad()
+    m.gain.grad = torch.ones(24)
+    assert _grad_dst([m.gain]) is None, "accumulation micro-step: autograd has to add"
 
 
 def test_settle_gathers_foreign_gradients_and_zeroes_missing_ones():
