@@ -59,7 +59,8 @@ def build_model(cfg_name: str, seq: int, rank: int, device, config: str = "text"
         p.requires_grad_(n.startswith("audio_embed"))
     if config == "int8":
         quantize_linear_(model.layers, "int8", dynamic_int8_act=True)  # quantise, then adapt (train_metamathqa.py:178-179)
-    apply_linear_adapter_(model.layers, "lora", rank=rank, alpha=float(rank))
+    if rank > 0:
+        apply_linear_adapter_(model.layers, "lora", rank=rank, alpha=float(rank))
     with torch.no_grad():
         for n, p in model.named_parameters():
             if n.endswith("lora_b"):
@@ -365,6 +366,66 @@ def run_workload(args, config: str, device, world: int, rank: int, steps: int, w
     return res
 
 
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s peak (a float4 copy reaches ~6.3 TB/s)
+
+
+def run_decode(args, device, steps: int, warmup: int, contexts=(4096, 8192)) -> dict:
+    """single-token decode of the 8B model against its KV cache (modelling/llama.py:76-90,126-127,189-207) - one hipGraph
+    replay per token (embedding, 32 x [norm+q|k|v+RoPE+cache write, split-cache attention, wo+residual, norm+gate|up+SwiGLU, w2+residual],
+    norm+head).  HBM-bound: every weight byte and every live K/V byte is read once per token; reported as ms/token and as the
+    fraction of the 8 TB/s HBM peak those algorithmic bytes make of the measured time."""
+    model, cfg = build_model(args.model, max(contexts), 0, device, "text")
+    model.requires_grad_(False)
+    model.eval()
+    model.build_cache(inference=True)  # host-built tables (bit parity of the RoPE table), then moved with the caches
+    model = model.to(device)
+    gen = torch.Generator(device=device)
+    gen.manual_seed(7)
+    for layer in model.layers:  # a cache full of plausible keys / values (a real prefill of 8k tokens is not what is measured here)
+        layer.attention.kv_cache.k_cache.normal_(0.0, 1.0, generator=gen)
+        layer.attention.kv_cache.v_cache.normal_(0.0, 1.0, generator=gen)
+    tok = torch.randint(0, cfg.vocab_size, (1, 1), device=device, generator=gen)
+    pos = torch.zeros(1, dtype=torch.int64, device=device)
+    weight_bytes = sum(p.numel() * p.element_size() for n, p in model.named_parameters() if not n.startswith("tok_embeddings")) + cfg.embed_dim * 2
+    out = {"workload": f"Llama-3.1-8B bf16 single-token decode (batch 1) against a KV cache of max_seq_len {max(contexts)}; random-init weights, "
+                       "random cache contents", "weight_bytes": weight_bytes, "launch": "hipGraph replay per token"}
+    with torch.no_grad():
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                model(tok, input_pos=pos)
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            logits = model(tok, input_pos=pos)
+        for ctx in contexts:
+            pos.fill_(ctx - 1)  # the token at position ctx-1 attends to ctx cached positions (its own k/v are written first)
+            for _ in range(warmup):
+                graph.replay()
+            torch.cuda.synchronize()
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+            ev[0].record()
+            for i in range(steps):
+                graph.replay()
+                ev[i + 1].record()
+            torch.cuda.synchronize()
+            per = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(steps))
+            ms = ev[0].elapsed_time(ev[steps]) / steps
+            kv_bytes = cfg.num_layers * 2 * cfg.num_kv_heads * ctx * cfg.head_dim * 2
+            gbs = (weight_bytes + kv_bytes) / (ms * 1e-3) / 1e9
+            out[f"ctx{ctx}"] = {"ms_per_token": round(ms, 4), "p50_ms": round(per[len(per) // 2], 4), "tokens_per_s": round(1e3 / ms, 1), "kv_bytes": kv_bytes,
+                                "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                                             "traffic": None, "algorithmic_bytes": weight_bytes + kv_bytes},
+                                "finite_logits": bool(torch.isfinite(logits.float()).all())}
+    del model, graph, logits
+    import gc
+
+    gc.collect()
+    torch.cuda.empty_cache()
+    return out
+
+
 def _summary(args, r: dict, world: int) -> dict:
     """Numbers of one workload: whole-job tokens/s, step times, the roofline of its dominant GEMM kernel (+ the i8 kernel's own when it ran)."""
     ms = r["elapsed"] / r["steps"] * 1e3
@@ -392,7 +453,7 @@ def main():
     ap.add_argument("--seq", type=int, default=4096)
     ap.add_argument("--rank", type=int, default=16)
     ap.add_argument("--model", default="llama31_8b", choices=["llama31_8b", "tiny"])
-    ap.add_argument("--config", default="text", choices=["text", "int8", "audio", "packed"],
+    ap.add_argument("--config", default="text", choices=["text", "int8", "audio", "packed", "decode"],
                     help="text: BASELINE configs[1] (headline); int8: configs[3] per-GPU (INT8 frozen base, dynamic int8 activations, i8 MFMA) ; "
                          "audio: configs[2] (mel+Conv1D prefix of seq/2 audio tokens + seq/2 text tokens, prefix-LM mask, audio_embed trainable)")
     ap.add_argument("--trainable", default="lora", choices=["lora", "reference"],
@@ -427,6 +488,14 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     S = args.seq
+    if args.config == "decode":  # inference extra, its own line: ms per decoded token against the HBM roofline
+        d = run_decode(args, device, args.steps, args.warmup)
+        best = d["ctx4096"]
+        print(json.dumps({"metric": "decode tokens/sec Llama-3.1-8B batch 1, KV cache 4096 (ms/token at 4096 and 8192)", "value": best["tokens_per_s"], "unit": "tokens/s",
+                          "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": best["ms_per_token"], "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "bf16", "data": "synthetic", "config": {"workload": d["workload"]}, "roofline": best["roofline"], "decode": d}),
+              flush=True)
+        return
     r = run_workload(args, args.config, device, world, rank, args.steps, args.warmup)
     extras = {}
     if world == 1 and args.config == "text" and args.trainable == "lora" and not args.no_extras and os.environ.get("LLX_FORCE_DP") != "1":
@@ -438,6 +507,12 @@ def main():
             except Exception as exc:  # noqa: BLE001 - an extra workload must not cost the headline line
                 extras[cfg] = {"error": f"{type(exc).__name__}: {exc}"}
                 print(f"[bench] extra workload {cfg} failed: {exc}", file=sys.stderr, flush=True)
+        if args.model == "llama31_8b":
+            try:
+                extras["decode"] = run_decode(args, device, 20, 5)
+            except Exception as exc:  # noqa: BLE001
+                extras["decode"] = {"error": f"{type(exc).__name__}: {exc}"}
+                print(f"[bench] extra workload decode failed: {exc}", file=sys.stderr, flush=True)
 
     if rank == 0:
         sm = _summary(args, r, world)

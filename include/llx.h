@@ -129,6 +129,37 @@ int llx_attn_dense_fwd(const void* q, int64_t q_sb, int64_t q_sh, int64_t q_ss, 
                        const void* mask, int64_t m_sb, int64_t m_sh, int64_t m_sq, int64_t B, int64_t H, int64_t KVH, int64_t Sq, int64_t Skv,
                        int64_t head_dim, float scale, llx_stream_t s);
 
+/* ---- decode path: a few query tokens (M <= 4) against the KV cache - modelling/llama.py:76-90 (KVCache), :126-127,:135-137 (cached
+ *      K/V through SDPA with the row-gathered causal mask), :189-194,:205-207 (Llama.forward with input_pos).  Every linear is a
+ *      weight stream: all CUs read weight rows once (llx_gemv_bf16), the call sites' neighbours ride in its prologue / epilogue. ---- */
+/* out = epilogue( [rmsnorm(x) | x][M, K] . [W0; W1; W2]^T ): F.linear at modelling/llama.py:118-120,140,152,216 for M <= 4 rows.
+ * W_s [n_s, K] bf16 row-major (ld = ldw_s; w1 / w2 nullable with n = 0; inner n_s % 4 == 0), K % 8 == 0; norm_w (nullable): nn.RMSNorm
+ * (:158-160,182) applied to x first.  epilogue 0: out [M, N] | 1: + res [M, N] (:172-173) | 2 (q|k|v): apply_rope (:63-73,122-123;
+ * table row = token index in this call, :207) on rows [0, n_q) -> out [M, n_q] and on rows [n_q, n_q + n_k) -> k cache, remaining
+ * rows -> v cache, both at input_pos[m] (device int64; KVCache.update :83-90; caches [KVH, Smax, 128] through (head, position)
+ * strides) | 3 (gate|up: W0, W1, N = 2 n_0): out [M, n_0] = silu(gate) * up (:150-152).  LoRA (modelling/lora.py:43; bext_s
+ * [n_s, rank_s] nullable, t [M, sum rank] bf16 = x . A^T from a previous call, rank % 8 == 0): out += lora_scale * t_s . bext_s[row]. */
+int llx_gemv_bf16(const void* w0, int64_t ldw0, int64_t n0, const void* w1, int64_t ldw1, int64_t n1, const void* w2, int64_t ldw2, int64_t n2,
+                  const void* x, int64_t ldx, int64_t M, int64_t K, const void* norm_w, float eps, int epilogue, void* out, int64_t ldo,
+                  const void* res, int64_t ldr, const float* rope, int64_t n_q, int64_t n_k, void* k_cache, void* v_cache, int64_t c_sh,
+                  int64_t c_ss, const int64_t* input_pos, const void* bext0, const void* bext1, const void* bext2, int64_t rank0, int64_t rank1,
+                  int64_t rank2, const void* t, int64_t ldt, float lora_scale, llx_stream_t s);
+/* *extent (device int) = 1 + the largest key index any of the `rows` bool mask rows (row stride in bytes) allows; 0 if none: the
+ * mask of the cached path is data (rows of a tril matrix gathered at input_pos, :194,:205), its extent sizes the decode key ranges. */
+int llx_mask_extent(const void* mask, int64_t row_stride, int64_t rows, int64_t Skv, int* extent, llx_stream_t s);
+/* KVCache.update (:83-90): cache[b, h, input_pos[l], :] = src[b, h, l, :] for k and v (sources share strides, caches share strides). */
+int llx_kv_scatter(const void* k, const void* v, int64_t s_sb, int64_t s_sh, int64_t s_ss, void* k_cache, void* v_cache, int64_t c_sb, int64_t c_sh,
+                   int64_t c_ss, const int64_t* input_pos, int64_t B, int64_t KVH, int64_t L, int64_t Smax, int64_t head_dim, llx_stream_t s);
+/* SDPA(q, k_cache, v_cache, mask, is_causal=False, enable_gqa=True) (:135-137) for M query tokens with M * H / KVH <= 16: the cache of a
+ * kv head is split over `nsplit` workgroups, the heads of its group share every K / V row read; partials merged in a second launch.
+ * q / o [B, H, M, 128], caches [B, KVH, Skv, 128] through (batch, head, position) strides; mask bool [.., M, Skv] with broadcast
+ * strides; extent nullable (llx_mask_extent); workspace fp32, llx_attn_decode_workspace_bytes(B, H, M, nsplit) bytes. */
+int64_t llx_attn_decode_workspace_bytes(int64_t B, int64_t H, int64_t M, int64_t nsplit);
+int llx_attn_decode(const void* q, int64_t q_sb, int64_t q_sh, int64_t q_ss, const void* k_cache, const void* v_cache, int64_t c_sb, int64_t c_sh,
+                    int64_t c_ss, void* o, int64_t o_sb, int64_t o_sh, int64_t o_ss, const void* mask, int64_t m_sb, int64_t m_sh, int64_t m_sq,
+                    const int* extent, float* workspace, int64_t B, int64_t H, int64_t KVH, int64_t M, int64_t Skv, int64_t nsplit,
+                    int64_t head_dim, float scale, llx_stream_t s);
+
 /* ---- RoPE: apply_rope at modelling/llama.py:63-73 (in place on the first `nheads` 128-wide heads of each row;
  *      table fp32 [S,64,2] from build_rope :54-60); backward = rotation by -theta. ----------------------------- */
 int llx_rope(const void* x, int64_t x_sb, int64_t x_ss, void* y, int64_t y_sb, int64_t y_ss, const float* table, int64_t B, int64_t S,

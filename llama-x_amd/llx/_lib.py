@@ -30,6 +30,12 @@ SIGNATURES: dict[str, tuple] = {
     "llx_attn_tile_flags": (c_int, [_P, _P, _P, _L, _L, _P]),
     "llx_attn_fwd": (c_int, [_P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _P, _P, _P, _L, _L, _L, _L, _L, _F, _P]),
     "llx_attn_dense_fwd": (c_int, [_P, _L, _L, _L, _P, _L, _L, _L, _P, _L, _L, _L, _P, _L, _L, _L, _P, _L, _L, _L, _L, _L, _L, _L, _L, _L, _F, _P]),
+    "llx_gemv_bf16": (c_int, [_P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _L, _L, _L, _P, _F, _I, _P, _L, _P, _L, _P, _L, _L, _P, _P, _L, _L, _P,
+                              _P, _P, _P, _L, _L, _L, _P, _L, _F, _P]),
+    "llx_mask_extent": (c_int, [_P, _L, _L, _L, _P, _P]),
+    "llx_kv_scatter": (c_int, [_P, _P, _L, _L, _L, _P, _P, _L, _L, _L, _P, _L, _L, _L, _L, _L, _P]),
+    "llx_attn_decode_workspace_bytes": (c_int64, [_L, _L, _L, _L]),
+    "llx_attn_decode": (c_int, [_P, _L, _L, _L, _P, _P, _L, _L, _L, _P, _L, _L, _L, _P, _L, _L, _L, _P, _P, _L, _L, _L, _L, _L, _L, _L, _F, _P]),
     "llx_attn_bwd_workspace_bytes": (c_int64, [_L, _L, _L, _L]),
     "llx_attn_bwd": (c_int, [_P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _P, _P, _L, _L, _P, _L, _L, _P, _L, _L,
                              _P, _P, _P, _P, _L, _L, _L, _L, _L, _F, _P]),

@@ -603,6 +603,110 @@ def attn_dense_fwd(q: Tensor, k: Tensor, v: Tensor, mask: Tensor) -> Tensor:
     return o
 
 
+# ------------------------------------------------------------------------------------------------- decode path (csrc/decode.hip)
+GV_NONE, GV_RESIDUAL, GV_QKV, GV_SWIGLU = 0, 1, 2, 3
+
+
+def gemv(ws: Sequence[Tensor], x: Tensor, *, norm: Optional[tuple[Tensor, float]] = None, epilogue: int = GV_NONE, out: Optional[Tensor] = None,
+         res: Optional[Tensor] = None, qkv: Optional[tuple] = None, lora: Optional[tuple] = None) -> Tensor:
+    """out = epilogue([rmsnorm(x) | x] @ cat(ws)^T) for M = x.shape[0] <= 4 rows: every CU streams weight rows (llx_gemv_bf16).
+    ws: 1-3 weights [n_s, K]; norm = (weight, eps); res [M, N] for GV_RESIDUAL; qkv = (rope_table, n_q, n_k, k_cache, v_cache, input_pos)
+    for GV_QKV (caches [1, KVH, Smax, 128]; returns q [M, n_q]); GV_SWIGLU returns h [M, n_0]; lora = (b factors, t [M, sum r], scale)."""
+    _chk_bf16(x, *ws)
+    M, Kd = x.shape
+    assert 1 <= len(ws) <= 3 and all(w.dim() == 2 and w.shape[1] == Kd and w.stride(1) == 1 for w in ws) and x.stride(1) == 1
+    ns = [w.shape[0] for w in ws] + [0] * (3 - len(ws))
+    N = sum(ns)
+    wp = [L.ptr(w) for w in ws] + [None] * (3 - len(ws))
+    lw = [w.stride(0) for w in ws] + [0] * (3 - len(ws))
+    n_out = {GV_NONE: N, GV_RESIDUAL: N, GV_QKV: qkv[1] if qkv else 0, GV_SWIGLU: ns[0]}[epilogue]
+    if out is None:
+        out = torch.empty(M, n_out, device=x.device, dtype=BF16)
+    assert out.shape == (M, n_out) and out.stride(1) == 1
+    nw, eps = (norm[0], float(norm[1])) if norm is not None else (None, 0.0)
+    rope = kc = vc = pos = None
+    n_q = n_k = c_sh = c_ss = 0
+    if epilogue == GV_QKV:
+        rope, n_q, n_k, kc, vc, pos = qkv
+        assert rope.dtype is torch.float32 and rope.is_contiguous() and rope.shape[0] >= M and rope.shape[1:] == (64, 2)
+        assert kc.shape == vc.shape and kc.dim() == 4 and kc.shape[0] == 1 and kc.shape[3] == 128 and kc.stride() == vc.stride() and kc.stride(3) == 1
+        assert pos.dtype is torch.int64 and pos.shape == (M,) and pos.is_contiguous() and pos.is_cuda
+        c_sh, c_ss = kc.stride(1), kc.stride(2)
+    if epilogue == GV_RESIDUAL:
+        assert res is not None and res.shape == (M, N) and res.stride(1) == 1 and res.dtype is BF16
+    bs, ranks, t, ldt, lscale = [None] * 3, [0] * 3, None, 0, 0.0
+    if lora is not None:
+        b_list, t, lscale = lora
+        assert len(b_list) == len(ws) and t.dtype is BF16 and t.shape[0] == M and t.stride(1) == 1
+        for i, b in enumerate(b_list):
+            assert b.dtype is BF16 and b.is_contiguous() and b.shape[0] == ns[i]
+            bs[i], ranks[i] = b, b.shape[1]
+        assert t.shape[1] == sum(ranks)
+        ldt = t.stride(0)
+    L.check(_lib().llx_gemv_bf16(wp[0], lw[0], ns[0], wp[1], lw[1], ns[1], wp[2], lw[2], ns[2], L.ptr(x), x.stride(0), M, Kd, L.ptr(nw), eps, epilogue,
+                                 L.ptr(out), out.stride(0), L.ptr(res), res.stride(0) if res is not None else 0, L.ptr(rope), n_q, n_k, L.ptr(kc), L.ptr(vc),
+                                 c_sh, c_ss, L.ptr(pos), L.ptr(bs[0]), L.ptr(bs[1]), L.ptr(bs[2]), ranks[0], ranks[1], ranks[2], L.ptr(t), ldt, float(lscale),
+                                 L.stream()), "llx_gemv_bf16")
+    return out
+
+
+def mask_extent(mask: Tensor) -> Tensor:
+    """Device int32 [1]: 1 + the largest key index any row of the bool mask [..., Skv] allows (0 if none)."""
+    L.require_cuda(mask)
+    assert mask.dtype is torch.bool
+    m2 = mask.reshape(-1, mask.shape[-1])
+    if m2.stride(1) != 1:
+        m2 = m2.contiguous()
+    ext = torch.empty(1, device=mask.device, dtype=torch.int32)
+    L.check(_lib().llx_mask_extent(L.ptr(m2), m2.stride(0), m2.shape[0], m2.shape[1], L.ptr(ext), L.stream()), "llx_mask_extent")
+    return ext
+
+
+def kv_scatter(k: Tensor, v: Tensor, k_cache: Tensor, v_cache: Tensor, input_pos: Tensor) -> None:
+    """k_cache[:, :, input_pos] = k ; v_cache[:, :, input_pos] = v  (KVCache.update, modelling/llama.py:83-90); k / v [B, KVH, L, 128] views."""
+    _chk_bf16(k, v, k_cache, v_cache)
+    L.require_cuda(input_pos)
+    B, KVH, Lq, hd = k.shape
+    assert v.shape == k.shape and k.stride() == v.stride() and k.stride(3) == 1 and k_cache.stride() == v_cache.stride() and k_cache.stride(3) == 1
+    assert k_cache.shape[0] == B and k_cache.shape[1] == KVH and k_cache.shape[3] == hd and input_pos.shape == (Lq,)
+    pos = input_pos.to(torch.int64).contiguous()
+    L.check(_lib().llx_kv_scatter(L.ptr(k), L.ptr(v), k.stride(0), k.stride(1), k.stride(2), L.ptr(k_cache), L.ptr(v_cache), k_cache.stride(0),
+                                  k_cache.stride(1), k_cache.stride(2), L.ptr(pos), B, KVH, Lq, k_cache.shape[2], hd, L.stream()), "llx_kv_scatter")
+
+
+_DECODE_WS: dict = {}
+
+
+def attn_decode(q: Tensor, k_cache: Tensor, v_cache: Tensor, mask: Tensor, extent: Optional[Tensor] = None, out: Optional[Tensor] = None) -> Tensor:
+    """SDPA over the cache for a few query tokens: q [B, H, M, 128] (any strides, last dim dense), caches [B, KVH, Skv, 128], bool mask
+    broadcastable to [B, H, M, Skv] -> o [B, H, M, 128] stored as [B, M, H*128] (the layout wo reads).  M * H / KVH <= 16."""
+    _chk_bf16(q, k_cache, v_cache)
+    L.require_cuda(mask)
+    B, H, M, hd = q.shape
+    KVH, Skv = k_cache.shape[1], k_cache.shape[2]
+    assert mask.dtype is torch.bool and mask.shape[-2:] == (M, Skv) and k_cache.stride() == v_cache.stride()
+    m = mask
+    while m.dim() < 4:
+        m = m.unsqueeze(0)
+    if m.stride(3) != 1:
+        m = m.contiguous()
+    m_sb = m.stride(0) if m.shape[0] != 1 else 0
+    m_sh = m.stride(1) if m.shape[1] != 1 else 0
+    nsplit = max(1, min(-(-Skv // 32), -(-256 // (B * KVH)), 64))
+    nbytes = _lib().llx_attn_decode_workspace_bytes(B, H, M, nsplit)
+    key = (q.device, torch.cuda.current_stream(q.device).cuda_stream)
+    ws = _DECODE_WS.get(key)
+    if ws is None or ws.numel() * 4 < nbytes:
+        ws = _DECODE_WS[key] = torch.empty(nbytes // 4, device=q.device, dtype=torch.float32)
+    if out is None:
+        out = torch.empty(B, M, H * hd, device=q.device, dtype=BF16)
+    o4 = out.view(B, M, H, hd)
+    L.check(_lib().llx_attn_decode(L.ptr(q), q.stride(0), q.stride(1), q.stride(2), L.ptr(k_cache), L.ptr(v_cache), k_cache.stride(0), k_cache.stride(1),
+                                   k_cache.stride(2), L.ptr(out), o4.stride(0), o4.stride(2), o4.stride(1), L.ptr(m), m_sb, m_sh, m.stride(2), L.ptr(extent),
+                                   L.ptr(ws), B, H, KVH, M, Skv, nsplit, hd, 1.0 / math.sqrt(hd), L.stream()), "llx_attn_decode")
+    return out
+
+
 # ------------------------------------------------------------------------------------------------- cross entropy
 def head_compact_index(labels: Tensor) -> tuple[Tensor, Tensor, Tensor, Tensor]:
     """(idx, inv, labels_c, count) for the labelled rows (labels != -100) in order; everything stays on the device."""

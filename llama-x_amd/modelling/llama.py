@@ -18,6 +18,7 @@ import torch
 from torch import Tensor, nn
 from torch.utils.checkpoint import checkpoint
 
+from llx import decode as D
 from llx import kernels as K
 from llx import ops
 from llx._lib import LlxError
@@ -126,8 +127,11 @@ class KVCache(nn.Module):
     def update(self, input_pos: Tensor, k: Tensor, v: Tensor):
         # input_pos: [S], k/v: [B, KVH, S, hd]
         assert input_pos.shape[0] == k.shape[2], (input_pos.shape, k.shape)
-        self.k_cache[:, :, input_pos] = k
-        self.v_cache[:, :, input_pos] = v
+        if k.is_cuda and k.dtype is torch.bfloat16 and k.shape[0] == self.k_cache.shape[0] and k.stride() == v.stride() and k.stride(3) == 1:
+            K.kv_scatter(k, v, self.k_cache, self.v_cache, input_pos)  # both caches from one HIP launch, straight from the q|k|v buffer's views
+        else:
+            self.k_cache[:, :, input_pos] = k
+            self.v_cache[:, :, input_pos] = v
         return self.k_cache, self.v_cache
 
 
@@ -191,8 +195,10 @@ class Attention(nn.Module):
             k, v = self.kv_cache.update(input_pos, k, v)
         if mask is None:  # no cache, no mask cannot reach here; a cache without mask attends to everything cached
             mask = torch.ones(L_, k.shape[2], dtype=torch.bool, device=x.device)
-        o = K.attn_dense_fwd(q, k, v, mask)  # [B,H,L,hd]
-        o2 = o.transpose(1, 2).reshape(B * L_, H * hd)
+        if L_ * (H // KVH) <= 16 and k.stride() == v.stride():  # a few query tokens over a long cache: split-cache decode kernel
+            o2 = K.attn_decode(q, k, v, mask, D.mask_extent(mask)).view(B * L_, H * hd)
+        else:
+            o2 = K.attn_dense_fwd(q, k, v, mask).transpose(1, 2).reshape(B * L_, H * hd)  # [B,H,L,hd] -> rows
         y, _ = ops.GroupPlan((self.wo,)).forward(o2, None, K._rows2d(x.contiguous()) if residual else None)
         return y.view(B, L_, -1)
 
@@ -233,6 +239,8 @@ class TransformerLayer(nn.Module):
     def forward(self, x: Tensor, rope: Tensor, *, mask: Tensor | None = None, input_pos: Tensor | None = None,
                 block_mask=None) -> Tensor:
         # x + attention(attention_norm(x)) and x + feed_forward(ffn_norm(x)), each as one fused autograd node
+        if D.layer_ok(self, x, mask) and not (torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))):
+            return D.layer_forward(self, x, _rope_f32(rope).contiguous(), mask, input_pos)  # decode: every linear a weight stream
         pa = pf = None
         if x.is_cuda and self.attention.kv_cache is None and mask is None:
             pa, pf = self.attention.plans(), self.feed_forward.plans()
@@ -268,6 +276,8 @@ class Llama(nn.Module):
 
     def _head(self, x: Tensor, labels: Tensor | None) -> Tensor:
         if labels is None:
+            if D.head_ok(self, x) and not (torch.is_grad_enabled() and (x.requires_grad or self.output.weight.requires_grad or self.norm.weight.requires_grad)):
+                return D.head_forward(self, x)
             return self.output(self.norm(x))
         plan = ops.LinearPlan(self.output)
         return ops.HeadLossFn.apply(x, self.norm.weight, labels, self.norm.eps, plan, *plan.tensors())

@@ -393,30 +393,57 @@ def _mask_for(kind, S):
     raise ValueError(kind)
 
 
-@pytest.mark.parametrize("S,kind", [(512, "causal"), (2048, "causal"), (4096, "causal"), (4096, "doc"), (4096, "prefix"), (8192, "causal")])
-def test_full_dimension_layer_parity(cuda, S, kind):
+@pytest.mark.parametrize("S,kind,base", [(512, "causal", "bf16"), (2048, "causal", "bf16"), (4096, "causal", "bf16"), (4096, "doc", "bf16"),
+                                         (4096, "prefix", "bf16"), (8192, "causal", "bf16"), (8192, "prefix", "bf16"), (8192, "mixed-prefix-b2", "bf16"),
+                                         (4096, "causal", "int8-dynamic"), (4096, "causal", "int8-weight-only")])
+def test_full_dimension_layer_parity(cuda, S, kind, base):
     """One TransformerLayer at the REAL Llama-3.1-8B dimensions (D 4096, 32/8 heads, I 14336, LoRA r=16) against the oracle, at
-    the sequence lengths BASELINE.json's configs run (S = 4096 headline, S = 8192 for configs[4]) and with the three mask kinds
-    (causal, packed-document, prefix-LM): exercises the production tile shapes (N = 6144 / 28672 fused groups with RoPE / SwiGLU
-    epilogues, K-extension, block-diagonal LoRA operands, GQA 4:1, 64-128-tile causal key sweeps, multi-round GEMM grids)."""
+    the sequence lengths BASELINE.json's configs run (S = 4096 headline, S = 8192 for configs[4]) and with the mask kinds they use
+    (causal, packed-document, prefix-LM, and configs[4]'s B = 2 batch with a different prefix length per sample): exercises the
+    production tile shapes (N = 6144 / 28672 fused groups with RoPE / SwiGLU epilogues, K-extension, block-diagonal LoRA operands,
+    GQA 4:1, 64-128-tile causal key sweeps, multi-round GEMM grids).  base = int8-*: configs[3]'s frozen INT8 base
+    (quantize_linear_ then the adapter, train_metamathqa.py:178-179) - dynamic: fused norm-quantiser, llx_int8_mm_dequant_ext with
+    RoPE / SwiGLU / residual epilogues and the scaled adapter gradient pass; weight-only: the bf16 GEMM on the widened int8 image
+    with the column-scale epilogue - against O.int8_linear per member linear."""
     from modelling import apply_linear_adapter_
-    from modelling.llama import LlamaConfig, TransformerLayer, build_rope
+    from modelling.llama import LlamaConfig, MaskSpec, TransformerLayer, build_rope
+    from subclasses import quantize_linear_
 
     cfg = O.LLAMA31_8B._replace(num_layers=1, max_seq_len=S)
     p = {k: v for k, v in O.init_params(cfg._replace(vocab_size=8)).items() if k.startswith("layers.0.")}
     p.update(O.init_lora(cfg, 16))
     pb, pf = bf16_params(p)
-    x = O.randn("x_full", (1, S, cfg.embed_dim), 0.5).bfloat16()
-    dy = O.randn("dy_full", (1, S, cfg.embed_dim), 0.1).bfloat16()
+    B = 2 if kind == "mixed-prefix-b2" else 1
+    x = O.randn("x_full", (B, S, cfg.embed_dim), 0.5).bfloat16()
+    dy = O.randn("dy_full", (B, S, cfg.embed_dim), 0.1).bfloat16()
+    if base != "bf16":  # oracle side: quantise the bf16 weights exactly as Int8LinearWeight.from_float does (scales in bf16)
+        for suf in O.LINEAR_SUFFIXES:
+            key = f"layers.0.{suf}"
+            q, sc = O.quantize_int8_rowwise(pb[key + ".weight"])
+            pf.pop(key + ".weight")
+            pf[key + ".int_data"], pf[key + ".scale"], pf[key + ".dynamic"] = q, sc.float(), base == "int8-dynamic"
     train = [k for k in pf if "lora_" in k or k.endswith("_norm.weight")]
     pr = {k: (v.clone().requires_grad_() if k in train else v) for k, v in pf.items()}
     xr = x.float().requires_grad_()
-    dense, spec = _mask_for(kind, S)
-    ref = O.layer(xr, pr, 0, cfg, O.rope_table(cfg)[:S], dense, 1.0)
-    ref.backward(dy.float())
+    if kind == "mixed-prefix-b2":  # configs[4]: per-sample prefix lengths {2048, 4096} in one batch
+        P = torch.tensor([2048, 4096])
+        spec = MaskSpec(prefix_len=P)
+        outs = []
+        for b in range(B):  # the oracle sample by sample (its [H, S, S] fp32 scores are 8.6 GB each); parameter gradients add up
+            ob = O.layer(xr[b : b + 1], pr, 0, cfg, O.rope_table(cfg)[:S], O.prefix_lm_mask(S, P[b : b + 1])[0, 0], 1.0)
+            ob.backward(dy[b : b + 1].float())
+            outs.append(ob.detach())
+        ref = torch.cat(outs)
+    else:
+        dense, spec = _mask_for(kind, S)
+        ref = O.layer(xr, pr, 0, cfg, O.rope_table(cfg)[:S], dense, 1.0)
+        ref.backward(dy.float())
+        ref = ref.detach()
 
     layer = TransformerLayer(LlamaConfig(**{f: getattr(cfg, f) for f in LlamaConfig._fields})).bfloat16()
     layer.load_state_dict({k[len("layers.0."):]: v for k, v in pb.items() if "lora_" not in k})
+    if base != "bf16":
+        quantize_linear_(layer, "int8", dynamic_int8_act=base == "int8-dynamic")
     apply_linear_adapter_(layer, "lora", rank=16, alpha=16.0)
     with torch.no_grad():
         for name, mod in layer.named_modules():
@@ -430,10 +457,11 @@ def test_full_dimension_layer_parity(cuda, S, kind):
     xg = x.to(cuda).requires_grad_()
     out = layer(xg, rope[:S], block_mask=spec)
     out.backward(dy.to(cuda))
-    _close(out.float().cpu(), ref.detach(), 0.02, "layer output at 8B dims")
-    _rows_close(out.float().cpu(), ref.detach(), "layer output rows")
-    _close(xg.grad.float().cpu(), xr.grad, 0.04, "dx at 8B dims")
-    _rows_close(xg.grad.float().cpu(), xr.grad, "dx rows", min_cos=0.998)
+    # a quantised base adds the activation quantiser's rounding steps on both sides of every linear: same bars, one notch wider on dx
+    _close(out.float().cpu(), ref, 0.02, "layer output at 8B dims")
+    _rows_close(out.float().cpu(), ref, "layer output rows")
+    _close(xg.grad.float().cpu(), xr.grad, 0.04 if base == "bf16" else 0.05, "dx at 8B dims")
+    _rows_close(xg.grad.float().cpu(), xr.grad, "dx rows", min_cos=0.998 if base == "bf16" else 0.997)
     for name, q in layer.named_parameters():
         if q.requires_grad:
             _close(q.grad.float().cpu(), pr["layers.0." + name].grad, 0.05, name)
