@@ -114,12 +114,15 @@ int llx_attn_fwd(const void* q, int64_t q_sb, int64_t q_ss, const void* k, int64
                  int64_t v_ss, void* o, int64_t o_sb, int64_t o_ss, float* lse, const int* doc_ids, const int* prefix_len,
                  const void* flags, int64_t B, int64_t S, int64_t H, int64_t KVH, int64_t head_dim, float scale, llx_stream_t s);
 int64_t llx_attn_bwd_workspace_bytes(int64_t B, int64_t S, int64_t H, int64_t KVH); /* delta + per-head dK/dV partials */
+int64_t llx_attn_bwd_ds_bytes(int64_t B, int64_t S, int64_t H); /* optional bf16 dS^T scratch [B,H,Sp,Sp], Sp = S rounded up to 128 */
 int llx_attn_bwd(const void* q, int64_t q_sb, int64_t q_ss, const void* k, int64_t k_sb, int64_t k_ss, const void* v, int64_t v_sb,
                  int64_t v_ss, const void* o, int64_t o_sb, int64_t o_ss, const void* d_o, int64_t do_sb, int64_t do_ss, const float* lse,
                  float* delta /* fp32 workspace, llx_attn_bwd_workspace_bytes() */, void* dq, int64_t dq_sb, int64_t dq_ss, void* dk, int64_t dk_sb, int64_t dk_ss,
                  void* dv, int64_t dv_sb, int64_t dv_ss, const int* doc_ids, const int* prefix_len, const void* flags,
-                 const float* rope /* nullable fp32 [>=S,64,2]: dq, dk leave already multiplied by apply_rope's transpose */, int64_t B,
-                 int64_t S, int64_t H, int64_t KVH, int64_t head_dim, float scale, llx_stream_t s);
+                 const float* rope /* nullable fp32 [>=S,64,2]: dq, dk leave already multiplied by apply_rope's transpose */,
+                 void* ds /* nullable scratch of llx_attn_bwd_ds_bytes(): dS^T makes one round trip through it and each of the five products
+                             (S, dP, dV, dK, dQ) is computed once; without it the dQ kernel recomputes S and dP */,
+                 int64_t B, int64_t S, int64_t H, int64_t KVH, int64_t head_dim, float scale, llx_stream_t s);
 
 /* ---- dense-mask attention forward (inference / KV-cache path): SDPA(q,k,v,mask,is_causal=False,enable_gqa=True) at
  *      modelling/llama.py:126-127,135-137 with mask = causal_mask[None,None,input_pos] (:194,:205).  q [B,H,Sq,128],

@@ -2,10 +2,21 @@
 //
 // Gradients of softmax(QK^T*scale + mask)V as autograd produces them for the reference's SDPA / FlexAttention
 // call (modelling/llama.py:129-137).  P is recomputed from Q, K and the forward's log2-sum-exp.  Deterministic:
-// no atomics.  Three launches:
+// no atomics.  Two routes:
+// (a) with a dS buffer (llx_attn_bwd's `ds`, llx_attn_bwd_ds_bytes): five products, each computed once
+//   0. attn_bwd_delta_kernel: delta[b,h,q] = sum_d dO.O and the sanitised -lse
+//   1. attn_bwd_dkv3_kernel<.., DS>: one workgroup = 128 keys x ONE query head, sweeps 64-row query tiles: S, dP, dV, dK - and
+//      stores dS^T (bf16, the very values its dK product consumes) as [key][query] rows                -> fp32 partial dK, dV; dS^T
+//   2. attn_dkv_reduce_kernel: sums the G per-head partials of a KV group                             -> dK, dV
+//   3. attn_bwd_dq2_kernel: dQ^T = K^T . dS^T as a plain tiled product over the stored dS^T (HBM-bound: the buffer is read once;
+//      the S and dP products of the stand-alone dQ kernel are gone)                                   -> dQ
+//   A one-pass kernel that also accumulates dQ needs a cross-workgroup sum of 0.57 GB of fp32 per layer at S = 4096 (438 us at the
+//   1.3 TB/s float-atomic rate; an ordered hand-off needs every key block of a head co-resident, 32 of them at B = 1): the bf16
+//   dS^T round trip is 0.54 GB written + read at the plain HBM rate and keeps the result deterministic.
+// (b) without the buffer: seven products in two kernels
 //   1. attn_bwd_dq_kernel: one workgroup = 128 query rows of one head, sweeps key tiles      -> dQ, and delta[b,h,q] = sum_d dO.O
-//   2. attn_bwd_dkv3_kernel: one workgroup = 128 keys x ONE query head, sweeps 64-row query tiles -> fp32 partial dK, dV
-//   3. attn_dkv_reduce_kernel: sums the G per-head partials of a KV group                    -> dK, dV
+//   2. attn_bwd_dkv3_kernel: as above without the dS^T store                                 -> fp32 partial dK, dV
+//   3. attn_dkv_reduce_kernel
 // MFMA orientation keeps the softmax row index where the row constants (lse, delta) are cheap:
 //   dq kernel : S^T = K.Q^T, dP^T = V.dO^T (query on the lane), dQ^T += K^T.dS^T with dS^T taken from the accumulator
 //               registers as the B operand and K^T read from the SAME LDS image by ds_read_b64_tr_b16.
@@ -13,6 +24,7 @@
 //               dK^T += Q^T.dS with P/dS from the accumulator registers and Q^T/dO^T by transposed LDS reads.
 // LDS images read both by rows and transposed use the dual-use swizzle  slot = chunk ^ (((row&3)<<2) | ((row>>2)&3)).
 #include "common.h"
+#include <mutex>
 
 #define HD 128
 #define BQ 128
@@ -50,6 +62,7 @@ struct AttnBwdArgs {
   const float* rope;  // nullable: fp32 table [>= S, 64, 2]; dq and dk leave the kernels already rotated by -theta (apply_rope's transpose)
   unsigned long long* stamps;  // diagnostic (normally null): s_memtime stamps of workgroup 0, wave 0 of the dK/dV kernel
   bf16_t* dq; bf16_t* dk; bf16_t* dv;
+  bf16_t* ds; int Sp;  // route (a): dS^T [B][H][Sp keys][Sp queries] bf16, Sp = S rounded up to 128
   int64_t q_sb, q_ss, k_sb, k_ss, v_sb, v_ss, o_sb, o_ss, do_sb, do_ss;
   int64_t dq_sb, dq_ss, dk_sb, dk_ss, dv_sb, dv_ss;
   const int* doc_ids; const int* prefix_len; const uint8_t* flags;
@@ -269,7 +282,7 @@ __device__ __forceinline__ uint32_t xor_imm(uint32_t a, int c) {
   return r;
 }
 
-template <bool GENERAL, bool STAMP = false>
+template <bool GENERAL, bool STAMP = false, bool DS = false>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv3_kernel(const AttnBwdArgs a, float* __restrict__ part) {
   extern __shared__ __attribute__((aligned(256))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -476,6 +489,19 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv3_kernel(const AttnBwdArgs
             dsb[e >> 3][e & 7] = (__bf16)(st[e] * (dp[e] - d4[e2]));
           }
         }
+        if constexpr (DS) {
+          // dS^T[key][query] for the dQ product: this lane's key row, the 16 query rows of k-step s.  A half-wave exchange turns the
+          // two 8-byte pieces per lane (rows 16s+4hh.., 16s+8+4hh..) into ONE 16-byte store: lanes 0-31 rows 16s..16s+7, lanes 32-63
+          // rows 16s+8..16s+15
+          bf16_t* drow = a.ds + (((int64_t)b * a.H + h) * a.Sp + key) * a.Sp + qt * DKV_QT + qb32 * 32 + 8 * hh;
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2) {
+            const u32x4_t w = __builtin_bit_cast(u32x4_t, dsb[s2]);
+            const auto r0 = __builtin_amdgcn_permlane32_swap(w[0], w[2], false, false);
+            const auto r1 = __builtin_amdgcn_permlane32_swap(w[1], w[3], false, false);
+            *reinterpret_cast<u32x4_t*>(drow + 16 * s2) = u32x4_t{r0[0], r1[0], r0[1], r1[1]};
+          }
+        }
         __builtin_amdgcn_sched_barrier(0);
         if (qb32 == 0) stamp();  // 5: dS + pack
         // ---- dV^T += dO^T.P, dK^T += Q^T.dS: step = (s2, db), the transposed fragments of the next step are in flight
@@ -520,6 +546,160 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv3_kernel(const AttnBwdArgs
   }
 }
 
+// ------------------------------------------------------------------------------------------ route (a): delta, dQ from stored dS^T
+// delta[b,h,q] = sum_d dO[b,q,h,d] * O[b,q,h,d] (fp32) and nlse = -lse with -inf rows sanitised to 0: the row constants of the
+// backward.  16 lanes per (row, head): one 16-byte chunk of O and dO each, butterfly over the 16 lanes.
+__global__ __launch_bounds__(256) void attn_bwd_delta_kernel(const AttnBwdArgs a) {
+  const int64_t idx = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);  // (b, q, h) flattened with h fastest
+  const int c = threadIdx.x & 15;
+  const int64_t total = (int64_t)a.B * a.S * a.H;
+  const int64_t i = idx < total ? idx : total - 1;
+  const int h = (int)(i % a.H);
+  const int64_t bq = i / a.H;
+  const int q = (int)(bq % a.S), b = (int)(bq / a.S);
+  const u32x4_t ov = *reinterpret_cast<const u32x4_t*>(a.o + (int64_t)b * a.o_sb + (int64_t)q * a.o_ss + h * HD + c * 8);
+  const u32x4_t dv = *reinterpret_cast<const u32x4_t*>(a.d_o + (int64_t)b * a.do_sb + (int64_t)q * a.do_ss + h * HD + c * 8);
+  float s = 0.f;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) s += bflo(ov[e]) * bflo(dv[e]) + bfhi(ov[e]) * bfhi(dv[e]);
+  s += __shfl_xor(s, 1, 64);
+  s += __shfl_xor(s, 2, 64);
+  s += __shfl_xor(s, 4, 64);
+  s += __shfl_xor(s, 8, 64);
+  if (c == 0 && idx < total) {
+    const int64_t o = ((int64_t)b * a.H + h) * a.S + q;
+    const float l = a.lse[o];
+    a.delta[o] = s;
+    a.nlse[o] = (l == -INFINITY) ? 0.f : -l;
+  }
+}
+
+// dQ^T[d][q] = sum_key K^T[d][key] . dS^T[key][q]: one workgroup = 128 query rows of one head (a wave owns 32), sweeping the key
+// tiles its mask class allows.  Both operands sit in LDS as [key][128] images with the dual-use swizzle and are read TRANSPOSED
+// (ds_read_b64_tr_b16): the contraction index (key) is the image row for both.  K tiles come from L2 (a kv head's K is 1 MB), dS^T
+// tiles stream from HBM exactly once - the kernel is bound by that stream, the MFMA pipe is ~1/4 busy.
+#define DQ2_STAGE_BYTES (2 * TILE_BYTES)
+#define DQ2_LDS_BYTES (3 * DQ2_STAGE_BYTES)
+
+template <bool GENERAL>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(const AttnBwdArgs a) {
+  extern __shared__ __attribute__((aligned(256))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nqb = (a.S + BQ - 1) / BQ, nkt = (a.S + BKV - 1) / BKV;
+  const int qb = nqb - 1 - blockIdx.y;  // heaviest blocks of every head first
+  const int h = blockIdx.x, b = blockIdx.z;
+  const int kvh = h / (a.H / a.KVH);
+  const int r = lane & 31, hh = lane >> 5;
+  const int qi = qb * BQ + wave * 32 + r;
+
+  const uint8_t* fl = GENERAL ? a.flags + ((int64_t)b * nqb + qb) * nkt : nullptr;
+  const int kt_end = GENERAL ? nkt : min(nkt, (qb * BQ + BQ + BKV - 1) / BKV);
+  auto tile_class = [&](int t) -> int {
+    if constexpr (GENERAL) return fl[t];
+    else return 1;
+  };
+  auto next_tile = [&](int t) {
+    while (t < kt_end && tile_class(t) == 0) ++t;
+    return t;
+  };
+  // causal arithmetic: the dK/dV kernel works on 64-row query tiles and never touches (query tile 2qb, key tile 2qb+1), so the first
+  // two waves (query rows 0..63 of the block) must not consume that quadrant of the buffer
+  const int my_last = GENERAL ? nkt : 2 * qb + (wave >> 1);
+
+  const int srow_in = lane >> 4, sslot = lane & 15;
+  const bf16_t* kbase = a.k + (int64_t)b * a.k_sb + kvh * HD;
+  const bf16_t* dbase = a.ds + ((int64_t)b * a.H + h) * a.Sp * a.Sp + qb * BQ;
+  uint32_t koff[4], doff[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = i * 16 + wave * 4 + srow_in;
+    koff[i] = (uint32_t)(((int64_t)row * a.k_ss + (sslot ^ dual_swz(row)) * 8) * 2);
+    doff[i] = (uint32_t)(((int64_t)row * a.Sp + (sslot ^ dual_swz(row)) * 8) * 2);
+  }
+  auto stage = [&](int buf, int t) {
+    char* sK = smem + buf * DQ2_STAGE_BYTES;
+    char* sD = sK + TILE_BYTES;
+    const char* dt = (const char*)(dbase + (int64_t)t * BKV * a.Sp);  // rows t*64 .. +63 < Sp always
+#pragma unroll
+    for (int i = 0; i < 4; ++i) __builtin_amdgcn_global_load_lds((gbl_void*)(dt + doff[i]), (lds_void*)(sD + (i * 16 + wave * 4) * 256), 16, 0, 0);
+    if (t * BKV + BKV <= a.S) {
+      const char* kt = (const char*)(kbase + (int64_t)t * BKV * a.k_ss);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) __builtin_amdgcn_global_load_lds((gbl_void*)(kt + koff[i]), (lds_void*)(sK + (i * 16 + wave * 4) * 256), 16, 0, 0);
+    } else {  // ragged last key tile: clamp the row (its dS^T rows are zero)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = i * 16 + wave * 4 + srow_in;
+        const int key = min(t * BKV + row, a.S - 1);
+        __builtin_amdgcn_global_load_lds((gbl_void*)(kbase + (int64_t)key * a.k_ss + (sslot ^ dual_swz(row)) * 8), (lds_void*)(sK + (i * 16 + wave * 4) * 256), 16, 0, 0);
+      }
+    }
+  };
+
+  f32x16_t dq[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) dq[i][e] = 0.f;
+
+  // three LDS stages: the tiles t+1 and t+2 are in flight while tile t is consumed (8 loads per thread and tile)
+  int t0 = next_tile(0);
+  int t1 = t0 < kt_end ? next_tile(t0 + 1) : kt_end;
+  if (t0 < kt_end) stage(0, t0);
+  if (t1 < kt_end) stage(1, t1);
+  int cur = 0;
+  while (t0 < kt_end) {
+    const int t2 = t1 < kt_end ? next_tile(t1 + 1) : kt_end;
+    if (t2 < kt_end) {
+      stage((cur + 2) % 3, t2);
+      asm volatile("s_waitcnt vmcnt(16)" ::: "memory");  // tile t0 has landed; t1 and t2 (8 loads each) stay in flight
+    } else if (t1 < kt_end) {
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    const char* sK = smem + cur * DQ2_STAGE_BYTES;
+    const char* sD = sK + TILE_BYTES;
+    if (t0 <= my_last) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8_t dsf = tr_frag(sD, 16 * ks, wave, lane);
+#pragma unroll
+        for (int db = 0; db < 4; ++db) dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(sK, 16 * ks, db, lane), dsf, dq[db], 0, 0, 0);
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // every wave is done reading stage `cur`: the next iteration's DMA may overwrite it
+    asm volatile("" ::: "memory");
+    cur = (cur + 1) % 3;
+    t0 = t1;
+    t1 = t2;
+  }
+
+  if (qi < a.S) {
+    bf16_t* op = a.dq + (int64_t)b * a.dq_sb + (int64_t)qi * a.dq_ss + h * HD;
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        u32x2_t pk;
+        pk[0] = pack_bf2(dq[db][4 * g4 + 0] * a.scale, dq[db][4 * g4 + 1] * a.scale);
+        pk[1] = pack_bf2(dq[db][4 * g4 + 2] * a.scale, dq[db][4 * g4 + 3] * a.scale);
+        if (a.rope) {  // gradient of apply_rope on the bf16-rounded dq, exactly as the stand-alone rope kernel computes it
+          const f32x4_t t = *reinterpret_cast<const f32x4_t*>(a.rope + ((int64_t)qi * 64 + ((32 * db + 8 * g4 + 4 * hh) >> 1)) * 2);
+          const float c0 = t[0], s0 = t[1] * -1.f, c1 = t[2], s1 = t[3] * -1.f;
+          const float x0 = bflo(pk[0]), x1 = bfhi(pk[0]), y0 = bflo(pk[1]), y1 = bfhi(pk[1]);
+          pk[0] = pack_bf2(x0 * c0 - x1 * s0, x1 * c0 + x0 * s0);
+          pk[1] = pack_bf2(y0 * c1 - y1 * s1, y1 * c1 + y0 * s1);
+        }
+        *reinterpret_cast<u32x2_t*>(op + 32 * db + 8 * g4 + 4 * hh) = pk;
+      }
+  }
+}
+
 // dk = bf16(scale * sum_g partK[g]) ; dv = bf16(sum_g partV[g]);  8 elements per thread.
 __global__ void attn_dkv_reduce_kernel(const AttnBwdArgs a, const float* __restrict__ part) {
   const int G = a.H / a.KVH;
@@ -552,7 +732,6 @@ __global__ void attn_dkv_reduce_kernel(const AttnBwdArgs a, const float* __restr
   *reinterpret_cast<u32x4_t*>(a.dv + b * a.dv_sb + (int64_t)key * a.dv_ss + kvh * HD + d) = ov;
 }
 
-static bool g_bwd_attr = false;
 static unsigned long long* g_bwd_stamps = nullptr;
 
 // Diagnostic: the next llx_attn_bwd calls run the dK/dV kernel build that writes s_memtime stamps (10 per query tile of
@@ -564,15 +743,43 @@ extern "C" int64_t llx_attn_bwd_workspace_bytes(int64_t B, int64_t S, int64_t H,
   return (2 * B * H * S + (H / KVH) * 2 * B * S * KVH * HD) * 4;
 }
 
+// bf16 dS^T buffer of route (a): [B][H][Sp][Sp] with Sp = S rounded up to 128 (only the tiles the mask allows are written and read).
+extern "C" int64_t llx_attn_bwd_ds_bytes(int64_t B, int64_t S, int64_t H) {
+  const int64_t Sp = cdiv64(S, 128) * 128;
+  return B * H * Sp * Sp * 2;
+}
+
+static int attn_bwd_set_attrs() {
+  static std::once_flag once;
+  static bool ok = false;
+  std::call_once(once, [] {
+    hipError_t e = hipSuccess;
+    auto set = [&](const void* f, int bytes) { if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes); };
+    set((const void*)attn_bwd_dq_kernel<false>, DQ_LDS_BYTES);
+    set((const void*)attn_bwd_dq_kernel<true>, DQ_LDS_BYTES);
+    set((const void*)attn_bwd_dq2_kernel<false>, DQ2_LDS_BYTES);
+    set((const void*)attn_bwd_dq2_kernel<true>, DQ2_LDS_BYTES);
+    set((const void*)attn_bwd_dkv3_kernel<true, false, false>, DKV3_LDS_BYTES);
+    set((const void*)attn_bwd_dkv3_kernel<false, false, false>, DKV3_LDS_BYTES);
+    set((const void*)attn_bwd_dkv3_kernel<true, false, true>, DKV3_LDS_BYTES);
+    set((const void*)attn_bwd_dkv3_kernel<false, false, true>, DKV3_LDS_BYTES);
+    set((const void*)attn_bwd_dkv3_kernel<false, true, false>, DKV3_LDS_BYTES);
+    ok = e == hipSuccess;
+  });
+  return ok ? LLX_OK : LLX_ERR_LAUNCH;
+}
+
 // delta: fp32 workspace of llx_attn_bwd_workspace_bytes() bytes.  All strides in elements.  flags as in llx_attn_fwd.
 // rope (nullable): fp32 table [>= S, 64, 2]; when given, q and k are the ROTATED projections and dq, dk come out as the
 // gradients of the un-rotated ones (apply_rope's transpose fused into the dQ epilogue and the dK/dV reduce).
+// ds (nullable): llx_attn_bwd_ds_bytes() bytes of scratch; when given, dS^T takes one round trip through it and every product of the
+// backward is computed once (route (a) at the top of this file); without it the dQ kernel recomputes S and dP.
 extern "C" int llx_attn_bwd(const void* q, int64_t q_sb, int64_t q_ss, const void* k, int64_t k_sb, int64_t k_ss, const void* v,
                             int64_t v_sb, int64_t v_ss, const void* o, int64_t o_sb, int64_t o_ss, const void* d_o, int64_t do_sb,
                             int64_t do_ss, const float* lse, float* delta, void* dq, int64_t dq_sb, int64_t dq_ss, void* dk,
                             int64_t dk_sb, int64_t dk_ss, void* dv, int64_t dv_sb, int64_t dv_ss, const int* doc_ids,
-                            const int* prefix_len, const void* flags, const float* rope, int64_t B, int64_t S, int64_t H, int64_t KVH,
-                            int64_t head_dim, float scale, hipStream_t stream) {
+                            const int* prefix_len, const void* flags, const float* rope, void* ds, int64_t B, int64_t S, int64_t H,
+                            int64_t KVH, int64_t head_dim, float scale, hipStream_t stream) {
   LLX_REQUIRE(q && k && v && o && d_o && lse && delta && dq && dk && dv, "llx_attn_bwd: null pointer");
   LLX_REQUIRE(head_dim == HD, "llx_attn_bwd: head_dim=%lld unsupported (only 128)", (long long)head_dim);
   LLX_REQUIRE(B > 0 && S > 0 && H > 0 && KVH > 0 && H % KVH == 0, "llx_attn_bwd: bad B/S/H/KVH");
@@ -583,41 +790,48 @@ extern "C" int llx_attn_bwd(const void* q, int64_t q_sb, int64_t q_ss, const voi
               "llx_attn_bwd: unaligned output");
   LLX_REQUIRE(!(doc_ids || prefix_len) || flags, "llx_attn_bwd: tile flags required with doc_ids/prefix_len");
   LLX_REQUIRE(!rope || (uintptr_t)rope % 16 == 0, "llx_attn_bwd: unaligned rope table");
-  if (!g_bwd_attr) {
-    hipError_t e1 = hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, DQ_LDS_BYTES);
-    hipError_t e4 = hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, DQ_LDS_BYTES);
-    hipError_t e5 = hipSuccess;
-    hipError_t e2 = hipFuncSetAttribute((const void*)attn_bwd_dkv3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV3_LDS_BYTES);
-    if (e2 == hipSuccess) e2 = hipFuncSetAttribute((const void*)attn_bwd_dkv3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV3_LDS_BYTES);
-    hipError_t e3 = hipSuccess;
-    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess || e5 != hipSuccess) { llx_set_error("llx_attn_bwd: cannot raise LDS limit"); return LLX_ERR_LAUNCH; }
-    g_bwd_attr = true;
-  }
+  LLX_REQUIRE(!ds || (uintptr_t)ds % 256 == 0, "llx_attn_bwd: the dS buffer must be 256-byte aligned");
+  LLX_REQUIRE(S < (1 << 24) && B * H < (1 << 16), "llx_attn_bwd: S or B*H too large");
+  if (attn_bwd_set_attrs() != LLX_OK) { llx_set_error("llx_attn_bwd: cannot raise LDS limit"); return LLX_ERR_LAUNCH; }
   AttnBwdArgs a;
   a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.o = (const bf16_t*)o; a.d_o = (const bf16_t*)d_o;
   a.lse = lse; a.delta = delta; a.nlse = delta + B * H * S; a.stamps = nullptr; a.rope = rope; a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk; a.dv = (bf16_t*)dv;
+  a.ds = (bf16_t*)ds; a.Sp = (int)(cdiv64(S, 128) * 128);
   a.q_sb = q_sb; a.q_ss = q_ss; a.k_sb = k_sb; a.k_ss = k_ss; a.v_sb = v_sb; a.v_ss = v_ss; a.o_sb = o_sb; a.o_ss = o_ss;
   a.do_sb = do_sb; a.do_ss = do_ss; a.dq_sb = dq_sb; a.dq_ss = dq_ss; a.dk_sb = dk_sb; a.dk_ss = dk_ss; a.dv_sb = dv_sb; a.dv_ss = dv_ss;
   a.doc_ids = doc_ids; a.prefix_len = prefix_len; a.flags = (doc_ids || prefix_len) ? (const uint8_t*)flags : nullptr;
   a.B = (int)B; a.S = (int)S; a.H = (int)H; a.KVH = (int)KVH;
   a.scale = scale; a.scale_log2 = scale * 1.4426950408889634f;
-  // dQ first: it also publishes delta = rowsum(dO . O) and the sanitised -lse that the dK/dV kernel stages from global memory
-  if (a.flags) hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, dim3((unsigned)H, (unsigned)cdiv64(S, BQ), (unsigned)B), dim3(256), DQ_LDS_BYTES, stream, a);
-  else hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, dim3((unsigned)H, (unsigned)cdiv64(S, BQ), (unsigned)B), dim3(256), DQ_LDS_BYTES, stream, a);
-  LLX_LAUNCH_CHECK("llx_attn_bwd(dq)");
-  {
-    float* part = delta + 2 * B * H * S;
-    const int64_t nkb = cdiv64(S, DKV2_KEYS);
-    if (g_bwd_stamps && !a.flags) {
-      a.stamps = g_bwd_stamps;
-      (void)hipFuncSetAttribute((const void*)attn_bwd_dkv3_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV3_LDS_BYTES);
-      hipLaunchKernelGGL((attn_bwd_dkv3_kernel<false, true>), dim3((unsigned)(nkb * B * H)), dim3(256), DKV3_LDS_BYTES, stream, a, part);
-    } else if (a.flags) hipLaunchKernelGGL(attn_bwd_dkv3_kernel<true>, dim3((unsigned)(nkb * B * H)), dim3(256), DKV3_LDS_BYTES, stream, a, part);
-    else hipLaunchKernelGGL(attn_bwd_dkv3_kernel<false>, dim3((unsigned)(nkb * B * H)), dim3(256), DKV3_LDS_BYTES, stream, a, part);
-    LLX_LAUNCH_CHECK("llx_attn_bwd(dkv)");
-    const int64_t plane = B * S * KVH * HD;
-    hipLaunchKernelGGL(attn_dkv_reduce_kernel, dim3((unsigned)cdiv64(plane / 8, 256)), dim3(256), 0, stream, a, (const float*)part);
-    LLX_LAUNCH_CHECK("llx_attn_bwd(dkv reduce)");
+  const dim3 qgrid((unsigned)H, (unsigned)cdiv64(S, BQ), (unsigned)B);
+  const bool use_ds = ds != nullptr && !g_bwd_stamps;
+  if (use_ds) {
+    hipLaunchKernelGGL(attn_bwd_delta_kernel, dim3((unsigned)cdiv64(B * S * H, 16)), dim3(256), 0, stream, a);
+    LLX_LAUNCH_CHECK("llx_attn_bwd(delta)");
+  } else {
+    // dQ first: it also publishes delta = rowsum(dO . O) and the sanitised -lse that the dK/dV kernel stages from global memory
+    if (a.flags) hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, qgrid, dim3(256), DQ_LDS_BYTES, stream, a);
+    else hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, qgrid, dim3(256), DQ_LDS_BYTES, stream, a);
+    LLX_LAUNCH_CHECK("llx_attn_bwd(dq)");
+  }
+  float* part = delta + 2 * B * H * S;
+  const int64_t nkb = cdiv64(S, DKV2_KEYS);
+  const dim3 kgrid((unsigned)(nkb * B * H));
+  if (use_ds) {
+    if (a.flags) hipLaunchKernelGGL((attn_bwd_dkv3_kernel<true, false, true>), kgrid, dim3(256), DKV3_LDS_BYTES, stream, a, part);
+    else hipLaunchKernelGGL((attn_bwd_dkv3_kernel<false, false, true>), kgrid, dim3(256), DKV3_LDS_BYTES, stream, a, part);
+  } else if (g_bwd_stamps && !a.flags) {
+    a.stamps = g_bwd_stamps;
+    hipLaunchKernelGGL((attn_bwd_dkv3_kernel<false, true, false>), kgrid, dim3(256), DKV3_LDS_BYTES, stream, a, part);
+  } else if (a.flags) hipLaunchKernelGGL((attn_bwd_dkv3_kernel<true, false, false>), kgrid, dim3(256), DKV3_LDS_BYTES, stream, a, part);
+  else hipLaunchKernelGGL((attn_bwd_dkv3_kernel<false, false, false>), kgrid, dim3(256), DKV3_LDS_BYTES, stream, a, part);
+  LLX_LAUNCH_CHECK("llx_attn_bwd(dkv)");
+  const int64_t plane = B * S * KVH * HD;
+  hipLaunchKernelGGL(attn_dkv_reduce_kernel, dim3((unsigned)cdiv64(plane / 8, 256)), dim3(256), 0, stream, a, (const float*)part);
+  LLX_LAUNCH_CHECK("llx_attn_bwd(dkv reduce)");
+  if (use_ds) {
+    if (a.flags) hipLaunchKernelGGL(attn_bwd_dq2_kernel<true>, qgrid, dim3(256), DQ2_LDS_BYTES, stream, a);
+    else hipLaunchKernelGGL(attn_bwd_dq2_kernel<false>, qgrid, dim3(256), DQ2_LDS_BYTES, stream, a);
+    LLX_LAUNCH_CHECK("llx_attn_bwd(dq from dS)");
   }
   return LLX_OK;
 }

@@ -304,7 +304,8 @@ extern "C" int llx_gemv_bf16(const void* w0, int64_t ldw0, int64_t n0, const voi
   // 2 workgroups of 4 waves per CU; the wave count is trimmed so that every wave gets the same number of row groups where possible
   const int64_t per_wave = cdiv64(groups, 2048);
   const int grid = (int)cdiv64(cdiv64(groups, per_wave), 4);
-  const size_t lds = (size_t)M * K * 2 + 64;
+  const int MT = M == 1 ? 1 : (M == 2 ? 2 : 4);  // the kernel build stages MT rows (row M-1 repeated)
+  const size_t lds = (size_t)MT * K * 2 + 64;
   LLX_REQUIRE(lds <= 64 * 1024, "llx_gemv_bf16: M * K too large for the LDS stage");
   switch (M) {
     case 1: return launch_gemv_m<1>(a, epilogue, grid, lds, stream);

@@ -37,8 +37,9 @@ SIGNATURES: dict[str, tuple] = {
     "llx_attn_decode_workspace_bytes": (c_int64, [_L, _L, _L, _L]),
     "llx_attn_decode": (c_int, [_P, _L, _L, _L, _P, _P, _L, _L, _L, _P, _L, _L, _L, _P, _L, _L, _L, _P, _P, _L, _L, _L, _L, _L, _L, _L, _F, _P]),
     "llx_attn_bwd_workspace_bytes": (c_int64, [_L, _L, _L, _L]),
+    "llx_attn_bwd_ds_bytes": (c_int64, [_L, _L, _L]),
     "llx_attn_bwd": (c_int, [_P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _P, _P, _L, _L, _P, _L, _L, _P, _L, _L,
-                             _P, _P, _P, _P, _L, _L, _L, _L, _L, _F, _P]),
+                             _P, _P, _P, _P, _P, _L, _L, _L, _L, _L, _F, _P]),
     "llx_embedding_fwd": (c_int, [_P, _P, _P, _L, _L, _L, _L, _L, _L, _P]),
     "llx_embedding_bwd": (c_int, [_P, _P, _P, _L, _L, _L, _L, _L, _L, _P]),
     "llx_rope": (c_int, [_P, _L, _L, _P, _L, _L, _P, _L, _L, _L, _L, _I, _P]),

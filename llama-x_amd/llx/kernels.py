@@ -555,6 +555,12 @@ def attn_fwd(q: Tensor, k: Tensor, v: Tensor, mask: Optional[MaskSpec] = None) -
     return o, lse
 
 
+import os as _os
+
+_ATTN_BWD_DS = _os.environ.get("LLX_ATTN_BWD_DS", "1") != "0"
+_ATTN_BWD_DS_MAX = int(float(_os.environ.get("LLX_ATTN_BWD_DS_MAX_GB", "16")) * 2**30)
+
+
 def attn_bwd(q: Tensor, k: Tensor, v: Tensor, o: Tensor, do: Tensor, lse: Tensor, dq: Tensor, dk: Tensor, dv: Tensor,
              mask: Optional[MaskSpec] = None, rope: Optional[Tensor] = None) -> None:
     """rope (fp32 table [>= S, 64, 2]): q, k are the rotated projections; dq, dk come out as gradients of the un-rotated ones."""
@@ -566,6 +572,13 @@ def attn_bwd(q: Tensor, k: Tensor, v: Tensor, o: Tensor, do: Tensor, lse: Tensor
     for t in (q, k, v, o, do, dq, dk, dv):
         assert t.stride(3) == 1 and t.stride(2) == hd
     delta = torch.empty(_lib().llx_attn_bwd_workspace_bytes(B, S, H, KVH) // 4, device=q.device, dtype=torch.float32)  # delta + dK/dV partials
+    # dS^T scratch (bf16 [B, H, Sp, Sp], 1.07 GB at S = 4096): with it every product of the backward is computed once; it lives for this
+    # call only (the caching allocator / graph pool hands the same block to every layer).  LLX_ATTN_BWD_DS=0 or a buffer above the cap
+    # (LLX_ATTN_BWD_DS_MAX_GB, default 16) selects the two-kernel route that recomputes S and dP for dQ.
+    ds = None
+    ds_bytes = _lib().llx_attn_bwd_ds_bytes(B, S, H)
+    if _ATTN_BWD_DS and ds_bytes <= _ATTN_BWD_DS_MAX:
+        ds = torch.empty(ds_bytes // 2, device=q.device, dtype=BF16)
     d = p = fl = None
     if mask is not None:
         mask = mask.prepared(B, S, q.device)
@@ -573,7 +586,8 @@ def attn_bwd(q: Tensor, k: Tensor, v: Tensor, o: Tensor, do: Tensor, lse: Tensor
     L.check(_lib().llx_attn_bwd(L.ptr(q), q.stride(0), q.stride(1), L.ptr(k), k.stride(0), k.stride(1), L.ptr(v), v.stride(0), v.stride(1),
                                 L.ptr(o), o.stride(0), o.stride(1), L.ptr(do), do.stride(0), do.stride(1), L.ptr(lse), L.ptr(delta),
                                 L.ptr(dq), dq.stride(0), dq.stride(1), L.ptr(dk), dk.stride(0), dk.stride(1), L.ptr(dv), dv.stride(0),
-                                dv.stride(1), L.ptr(d), L.ptr(p), L.ptr(fl), L.ptr(rope), B, S, H, KVH, hd, 1.0 / math.sqrt(hd), L.stream()),
+                                dv.stride(1), L.ptr(d), L.ptr(p), L.ptr(fl), L.ptr(rope), L.ptr(ds), B, S, H, KVH, hd, 1.0 / math.sqrt(hd),
+                                L.stream()),
             "llx_attn_bwd")
 
 

@@ -482,6 +482,47 @@ def test_attention_random_shapes(K, cuda):
             torch.testing.assert_close(got.float(), want, atol=5e-2, rtol=5e-2, msg=lambda m, n=name: f"{tag} {n}: {m}")
 
 
+@pytest.mark.parametrize("B,S,H,KVH,kind", [(1, 1024, 8, 2, "causal"), (2, 449, 4, 1, "causal"), (1, 705, 4, 2, "docprefix"), (2, 640, 4, 4, "prefix"),
+                                            (1, 2048, 8, 2, "doc")])
+def test_attention_backward_routes_agree(K, cuda, B, S, H, KVH, kind):
+    """llx_attn_bwd with the dS^T scratch (five products, dQ as a tiled product over the stored dS^T) and without it (the dQ kernel
+    recomputes S and dP): dK / dV come from the same kernel arithmetic and must be BIT-identical, dQ sums the same bf16 dS values
+    over the keys in a different association and must agree to fp32 summation order; both meet the oracle; both are deterministic.
+    Sequence lengths that are not tile multiples exercise the padded dS^T rows / columns and the ragged last key tile."""
+    q = _bf(O.randn("rq", (B, S, H, 128))).to(cuda)
+    k = _bf(O.randn("rk", (B, S, KVH, 128))).to(cuda)
+    v = _bf(O.randn("rv", (B, S, KVH, 128))).to(cuda)
+    do = _bf(O.randn("rdo", (B, S, H, 128))).to(cuda)
+    mask, doc, prefix = _masks(kind, B, S)
+    ms = K.MaskSpec(doc, prefix) if (doc is not None or prefix is not None) else None
+    qr, kr, vr = (t.float().requires_grad_() for t in (q, k, v))
+    O.sdpa(qr.transpose(1, 2), kr.transpose(1, 2), vr.transpose(1, 2), mask.to(cuda)).transpose(1, 2).backward(do.float())
+    o, lse = K.attn_fwd(q, k, v, ms)
+    rope = O.rope_table(O.TINY._replace(max_seq_len=S)).to(cuda)
+    out = {}
+    for route in (True, False):
+        old = K._ATTN_BWD_DS
+        K._ATTN_BWD_DS = route
+        try:
+            for rp in (None, rope):
+                grads = []
+                for _ in range(2):
+                    dq, dk, dv = torch.full_like(q, float("nan")), torch.full_like(k, float("nan")), torch.full_like(v, float("nan"))
+                    K.attn_bwd(q, k, v, o, do, lse, dq, dk, dv, ms, rope=rp)
+                    grads.append((dq, dk, dv))
+                assert all(torch.equal(a, b) for a, b in zip(*grads)), "bit-identical reruns"
+                out[(route, rp is not None)] = grads[0]
+        finally:
+            K._ATTN_BWD_DS = old
+    for rp in (False, True):
+        (dq_a, dk_a, dv_a), (dq_b, dk_b, dv_b) = out[(True, rp)], out[(False, rp)]
+        assert torch.equal(dk_a, dk_b) and torch.equal(dv_a, dv_b), "dK / dV do not depend on the route"
+        torch.testing.assert_close(dq_a.float(), dq_b.float(), atol=2e-2, rtol=2e-2)
+    dq, dk, dv = out[(True, False)]
+    for name, got, want in (("dq", dq, qr.grad), ("dk", dk, kr.grad), ("dv", dv, vr.grad)):
+        torch.testing.assert_close(got.float(), want, atol=5e-2, rtol=5e-2, msg=lambda m, n=name: f"{n}: {m}")
+
+
 def test_attention_mask_bits_exact(K, cuda):
     """The mask rule itself is integer work: with V = one-hot-ish rows the set of attended keys is recovered exactly."""
     B, S, H = 1, 256, 1

@@ -457,16 +457,24 @@ def test_full_dimension_layer_parity(cuda, S, kind, base):
     xg = x.to(cuda).requires_grad_()
     out = layer(xg, rope[:S], block_mask=spec)
     out.backward(dy.to(cuda))
-    # a quantised base adds the activation quantiser's rounding steps on both sides of every linear: same bars, one notch wider on dx
-    _close(out.float().cpu(), ref, 0.02, "layer output at 8B dims")
-    _rows_close(out.float().cpu(), ref, "layer output rows")
-    _close(xg.grad.float().cpu(), xr.grad, 0.04 if base == "bf16" else 0.05, "dx at 8B dims")
-    _rows_close(xg.grad.float().cpu(), xr.grad, "dx rows", min_cos=0.998 if base == "bf16" else 0.997)
+    # Dynamic int8 activations: the oracle runs in fp32, the product rounds every activation to bf16 before the row-wise quantiser, so
+    # a few per cent of the int8 codes differ by one step between the two - a difference of the size of the quantisation noise itself
+    # (the heavy-tailed silu(g)*u rows carry ~3 % of it).  The max-norm bars widen accordingly; the per-row cosine bars stay tight
+    # enough to catch any structural error (a wrong scale, a dropped row block, a mis-rotated head).
+    dyn = base == "int8-dynamic"
+    t_out, t_dx, t_g = (0.06, 0.08, 0.08) if dyn else (0.02, 0.04, 0.05)
+    c_out, c_dx, c_g = (0.998, 0.995, 0.99) if dyn else (0.999, 0.998, 0.995)
+    o_cpu, dx_cpu = out.float().cpu(), xg.grad.float().cpu()
+    print(f"[{S}-{kind}-{base}] out err {(o_cpu - ref).abs().max() / ref.abs().max():.4f}, dx err {(dx_cpu - xr.grad).abs().max() / xr.grad.abs().max():.4f}")
+    _close(o_cpu, ref, t_out, "layer output at 8B dims")
+    _rows_close(o_cpu, ref, "layer output rows", min_cos=c_out)
+    _close(dx_cpu, xr.grad, t_dx, "dx at 8B dims")
+    _rows_close(dx_cpu, xr.grad, "dx rows", min_cos=c_dx)
     for name, q in layer.named_parameters():
         if q.requires_grad:
-            _close(q.grad.float().cpu(), pr["layers.0." + name].grad, 0.05, name)
+            _close(q.grad.float().cpu(), pr["layers.0." + name].grad, t_g, name)
             if q.grad.dim() == 2:
-                _rows_close(q.grad.float().cpu(), pr["layers.0." + name].grad, name, min_cos=0.995)
+                _rows_close(q.grad.float().cpu(), pr["layers.0." + name].grad, name, min_cos=c_g)
     # determinism at full size: a second run is bit-identical (no atomics anywhere on the path)
     xg2 = x.to(cuda).requires_grad_()
     for q in layer.parameters():
