@@ -338,8 +338,10 @@ def run_workload(args, config: str, device, world: int, rank: int, steps: int, w
     # ---- live roofline of the GEMM kernels: one more step with HIP events around every launch (on the launch stream).
     # Every rank runs the step (it contains the gradient exchange); only rank 0 records events.
     gemm_stats = {}
+    attn_stats = {}
     if rank == 0:
         K.GEMM_TRACE = []
+        K.ATTN_TRACE = []
     if not dp:
         buckets.zero_grad()
     eager_step()  # traced eagerly (events between launches), same kernels and shapes as the timed steps
@@ -347,6 +349,11 @@ def run_workload(args, config: str, device, world: int, rank: int, steps: int, w
     if rank == 0:
         tr = K.GEMM_TRACE
         K.GEMM_TRACE = None
+        at, K.ATTN_TRACE = K.ATTN_TRACE, None
+        for kind in ("fwd", "bwd"):
+            sel = [e for e in at if e[2] == kind]
+            if sel:
+                attn_stats[kind] = {"calls": len(sel), "ms": sum(e[0].elapsed_time(e[1]) for e in sel), "B": sel[0][3], "S": sel[0][4], "H": sel[0][5]}
         for kind in ("bf16", "i8"):
             sel = [e for e in tr if e[4] == kind]
             if sel:
@@ -355,7 +362,7 @@ def run_workload(args, config: str, device, world: int, rank: int, steps: int, w
                 gemm_stats[kind] = {"launches": sum(e[5] for e in sel), "calls": len(sel), "ms": sum(e[0].elapsed_time(e[1]) for e in sel),
                                     "flops": sum(e[2] for e in sel), "alg_bytes": sum(e[3] for e in sel)}
     res = {"config": config, "elapsed": elapsed, "steps": steps, "warmup": warmup, "per_step": per_step, "loss": float(loss.detach()),
-           "launch": launch_mode, "gemm": gemm_stats, "info": info, "S": S}
+           "launch": launch_mode, "gemm": gemm_stats, "attn": attn_stats, "info": info, "S": S}
     # release the 16 GB of weights + cached images + graph pools before the next workload is built
     del step, eager_step, run_model, model, optim, buckets, trainable
     graph = opt_graph = static_loss = stepper = None  # noqa: F841
@@ -436,6 +443,20 @@ def _summary(args, r: dict, world: int) -> dict:
          "workload": (WORKLOAD_TEXT[r["config"]].format(rank=args.rank, S=r["S"], **r["info"]) if args.model == "llama31_8b"
                       else f"tiny plumbing config seq={r['S']} ({r['config']})"),
          "labelled_positions": r["info"]["labelled"]}
+    at = r.get("attn") or {}
+    if "fwd" in at and "bwd" in at and r["config"] in ("text", "int8"):
+        # attention kernels against the bf16 MFMA peak on ALGORITHMIC FLOPs: causal mask -> half of the S x S score matrix; forward
+        # 2 products (QK^T, PV), backward 5 (S, dP, dV, dK, dQ - recomputation and whatever else the kernels execute is not counted)
+        B_, S_, H_ = at["fwd"]["B"], at["fwd"]["S"], at["fwd"]["H"]
+        per_product = 2.0 * B_ * H_ * S_ * S_ * 128 / 2
+        fl = {"fwd": 2 * per_product * at["fwd"]["calls"], "bwd": 5 * per_product * at["bwd"]["calls"]}
+        tot_ms = at["fwd"]["ms"] + at["bwd"]["ms"]
+        ach = (fl["fwd"] + fl["bwd"]) / (tot_ms * 1e-3) / 1e12
+        d["roofline_attn"] = {"bound": "mfma", "achieved": round(ach, 1), "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / BF16_DENSE_PEAK_TFLOPS, 4),
+                              "traffic": None, "kernel": "attn_fwd_kernel + llx_attn_bwd (delta, dK/dV + dS^T store, reduce, dQ) - causal, algorithmic FLOPs",
+                              "fwd_us_per_layer": round(at["fwd"]["ms"] * 1e3 / at["fwd"]["calls"], 1), "bwd_us_per_layer": round(at["bwd"]["ms"] * 1e3 / at["bwd"]["calls"], 1),
+                              "fwd_tflops": round(fl["fwd"] / (at["fwd"]["ms"] * 1e-3) / 1e12, 1), "bwd_tflops": round(fl["bwd"] / (at["bwd"]["ms"] * 1e-3) / 1e12, 1),
+                              "attn_ms_per_step": round(tot_ms, 2)}
     g = {k: v for k, v in r["gemm"].items() if v["ms"] > 0}
     if g:
         dominant = max(g, key=lambda k: g[k]["ms"])  # the kernel the step spends most of its time in
@@ -531,8 +552,15 @@ def main():
         }
         gf = GF_PER_TOKEN.get(S)
         if gf and args.model == "llama31_8b" and args.config == "text":
-            out["step_mfma_frac"] = round(gf * 1e9 * S / (sm["ms_per_step"] * 1e-3) / 1e12 / BF16_DENSE_PEAK_TFLOPS, 4)
-        for k in ("roofline", "roofline_i8"):
+            # FLOPs the step REQUIRES: SURVEY 8d's 34.0 GF/token prices the frozen LM head (forward + d hidden = 4 x 525.3 M FLOPs per
+            # position) on every position; ignore_index positions need neither (modelling/llama.py:216-218), so the head is priced on
+            # the labelled positions only when the compacted head runs (all positions with LLX_HEAD_COMPACT=0 or a trainable head)
+            head_gf = 4 * 4096 * 128_256 / 1e9
+            rows = sm["labelled_positions"] if out["config"]["lm_head_rows"] == "labelled only" else S
+            step_tf = ((gf - head_gf) * S + head_gf * rows) * 1e9 / 1e12
+            out["step_mfma_frac"] = round(step_tf / (sm["ms_per_step"] * 1e-3) / BF16_DENSE_PEAK_TFLOPS, 4)
+            out["step_algorithmic_tflop"] = round(step_tf, 2)
+        for k in ("roofline", "roofline_i8", "roofline_attn"):
             if k in sm:
                 out[k] = sm[k]
         if extras:

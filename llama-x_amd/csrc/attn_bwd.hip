@@ -25,6 +25,8 @@
 // LDS images read both by rows and transposed use the dual-use swizzle  slot = chunk ^ (((row&3)<<2) | ((row>>2)&3)).
 #include "common.h"
 #include <mutex>
+#include <stdlib.h>
+#include <type_traits>
 
 #define HD 128
 #define BQ 128
@@ -56,13 +58,34 @@ __device__ __forceinline__ bf16x8_t row_frag(const char* img, int row, int ks, i
   return *reinterpret_cast<const bf16x8_t*>(img + row * 256 + (((2 * ks + hh) ^ dual_swz(row)) << 4));
 }
 
+// (the 10-destination wait of the dQ-from-dS kernel; lds_tr_read / frag_of: common.h)
+template <int N>
+__device__ __forceinline__ void lds_tr_wait(s16x4_t& a, s16x4_t& b, s16x4_t (&c)[4], s16x4_t (&d)[4]) {
+  asm volatile("s_waitcnt lgkmcnt(%10)"
+               : "+v"(a), "+v"(b), "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3])
+               : "n"(N));
+  __builtin_amdgcn_sched_barrier(0);
+}
+// a ^ c issued where it is written: as plain C++ hipcc computes all the XORed addresses of a tile up front and keeps them live
+__device__ __forceinline__ uint32_t xor_imm(uint32_t a, int c) {
+  if (c == 0) return a;
+  uint32_t r;
+  asm volatile("v_xor_b32 %0, %1, %2" : "=v"(r) : "n"(c), "v"(a));
+  return r;
+}
+
 struct AttnBwdArgs {
   const bf16_t* q; const bf16_t* k; const bf16_t* v; const bf16_t* o; const bf16_t* d_o;
   const float* lse; float* delta; float* nlse;
   const float* rope;  // nullable: fp32 table [>= S, 64, 2]; dq and dk leave the kernels already rotated by -theta (apply_rope's transpose)
   unsigned long long* stamps;  // diagnostic (normally null): s_memtime stamps of workgroup 0, wave 0 of the dK/dV kernel
   bf16_t* dq; bf16_t* dk; bf16_t* dv;
-  bf16_t* ds; int Sp;  // route (a): dS^T [B][H][Sp keys][Sp queries] bf16, Sp = S rounded up to 128
+  int probe;           // timing probes of the dQ-from-dS kernel (LLX_DQ2_PROBE; results are wrong): 1 = every dS^T tile read from tile 0, 2 = no MFMA / LDS reads
+  bf16_t* ds; int Sp;  // route (a): dS^T per (b, h) as [Sp/64 key tiles][Sp/128 query blocks] tiles of 64 keys x 128 queries bf16 (16 KiB, each
+                       // written by one key-block workgroup and read by one query-block workgroup), Sp = S rounded up to 256.  Inside a
+                       // tile the 16-byte chunks (8 queries of one key) are ordered as the dK/dV kernel emits them, so that each of its
+                       // store instructions writes 1 KiB contiguously: chunk(key, q) = ((((kh*2 + qh)*2 + qb32)*2 + s)*2 + hh)*32 + r with
+                       // key = 32 kh + r, q = 64 qh + 32 qb32 + 16 s + 8 hh + (0..7)
   int64_t q_sb, q_ss, k_sb, k_ss, v_sb, v_ss, o_sb, o_ss, do_sb, do_ss;
   int64_t dq_sb, dq_ss, dk_sb, dk_ss, dv_sb, dv_ss;
   const int* doc_ids; const int* prefix_len; const uint8_t* flags;
@@ -76,7 +99,7 @@ struct AttnBwdArgs {
 
 template <bool GENERAL>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnBwdArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+  extern __shared__ __attribute__((aligned(256))) char smem[];  // 256-aligned: the transposed-read addresses flip bits 5-7 by XOR
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nqb = (a.S + BQ - 1) / BQ, nkt = (a.S + BKV - 1) / BKV;
@@ -163,6 +186,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnBwdArgs a
     }
   };
 
+  // lane constant of the transposed K reads (element map of tr_frag): byte offset of the lo 4-row block of d-block 0 in the first
+  // 16-key step of a 32-key half.  d-block db flips chunk bits 2-3 (byte XOR db << 6); the hi block sits 8 rows further and its
+  // swizzle differs in chunk bit 1 (byte XOR 0x20): ONE register instead of eight (this kernel has none to spare)
+  const uint32_t sbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  uint32_t aK0;
+  {
+    const int tq2 = (lane & 15) >> 2, tp = lane & 3, tsub = (lane >> 4) & 1;
+    const int rlo = 4 * hh + tq2;
+    aK0 = (uint32_t)(rlo * 256 + (((2 * tsub + (tp >> 1)) ^ dual_swz(rlo)) << 4) + ((tp & 1) << 3));
+  }
   f32x16_t dq[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -216,15 +249,26 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnBwdArgs a
       // dS^T = P^T * (dP^T - delta)
 #pragma unroll
       for (int e = 0; e < 16; ++e) st[e] = st[e] * (dp[e] - my_delta);
+      // dQ^T += K^T . dS^T: K^T fragments by transposed reads issued as inline asm (common.h: lds_tr_read - through the builtin hipcc
+      // drains the next tile's LDS-DMA right here); the 8 reads of the second 16-key step fly under the MFMAs of the first
+      {
+        // (the stage / half offsets are multiples of 8192: they do not touch the bits the XORs flip)
+        const uint32_t kb_ = sbase + cur * DQ_STAGE_BYTES + kb * 8192 + aK0;
+        s16x4_t Kl[4], Kh[4];  // one step's fragments at a time: this kernel has no registers to spare for a second set
 #pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        bf16x8_t dsb;
+        for (int s = 0; s < 2; ++s) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) dsb[j] = (__bf16)st[8 * s + j];
+          for (int db = 0; db < 4; ++db) {
+            if (s == 0) { lds_tr_read<0>(Kl[db], xor_imm(kb_, db << 6)); lds_tr_read<2048>(Kh[db], xor_imm(kb_, (db << 6) | 0x20)); }
+            else { lds_tr_read<4096>(Kl[db], xor_imm(kb_, db << 6)); lds_tr_read<4096 + 2048>(Kh[db], xor_imm(kb_, (db << 6) | 0x20)); }
+          }
+          bf16x8_t dsb;
 #pragma unroll
-        for (int db = 0; db < 4; ++db) {
-          bf16x8_t kt_f = tr_frag(sK, kb * 32 + s * 16, db, lane);
-          dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kt_f, dsb, dq[db], 0, 0, 0);
+          for (int j = 0; j < 8; ++j) dsb[j] = (__bf16)st[8 * s + j];
+          lds_tr_wait8<0>(Kl, Kh);
+#pragma unroll
+          for (int db = 0; db < 4; ++db) dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_of(Kl[db], Kh[db]), dsb, dq[db], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
     }
@@ -273,14 +317,6 @@ typedef __attribute__((address_space(3))) char lds_char;
 typedef __attribute__((address_space(3))) bf16x8_t lds_bf16x8;
 typedef __attribute__((address_space(3))) f32x4_t lds_f32x4;
 #define DKV3_LDS_BYTES (0x10000 + 1024)
-
-// a ^ c issued where it is written: as plain C++ hipcc computes all the XORed addresses of a tile up front and keeps them live
-__device__ __forceinline__ uint32_t xor_imm(uint32_t a, int c) {
-  if (c == 0) return a;
-  uint32_t r;
-  asm volatile("v_xor_b32 %0, %1, %2" : "=v"(r) : "n"(c), "v"(a));
-  return r;
-}
 
 template <bool GENERAL, bool STAMP = false, bool DS = false>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv3_kernel(const AttnBwdArgs a, float* __restrict__ part) {
@@ -416,14 +452,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv3_kernel(const AttnBwdArgs
       auto rowf = [&](int qb32, int img, int ks) -> bf16x8_t {
         return *(lds_bf16x8*)((lds_char*)(uintptr_t)xor_imm(Lr, ks << 5) + qb32 * 8192 + img * 0x4000);
       };
-      auto trf = [&](int qb32, int img, int step) -> bf16x8_t {  // step = (s2, db)
+      // transposed fragments as inline asm reads (common.h: lds_tr_read - through the builtin hipcc drains the next tile's LDS-DMA in
+      // front of the first transposed read of every half tile); step = (s2, db); the lo / hi 4-row blocks land in tl / th
+      auto trf = [&](int qb32, int img, int step, s16x4_t& tl, s16x4_t& th) {
         const int s2 = step >> 2, db = step & 3;
-        lds_char* plo = (lds_char*)(uintptr_t)xor_imm(Tl, db << 6) + (qb32 * 32 + s2 * 16) * 256 + img * 0x4000;
-        lds_char* phi = (lds_char*)(uintptr_t)xor_imm(Th, db << 6) + (qb32 * 32 + s2 * 16) * 256 + img * 0x4000;
-        const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)plo);
-        const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)phi);
-        const s16x8_t v8 = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        return __builtin_bit_cast(bf16x8_t, v8);
+        lds_tr_read_rt(tl, xor_imm(Tl, db << 6), (qb32 * 32 + s2 * 16) * 256 + img * 0x4000);
+        lds_tr_read_rt(th, xor_imm(Th, db << 6), (qb32 * 32 + s2 * 16) * 256 + img * 0x4000);
       };
 #pragma unroll
       for (int qb32 = 0; qb32 < 2; ++qb32) {
@@ -473,9 +507,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv3_kernel(const AttnBwdArgs
         }
         if (qb32 == 0) stamp();  // 4: dP chain
         // first transposed fragments of the second phase fly under the dS arithmetic
-        bf16x8_t td[2], tqf[2];
-        td[0] = trf(qb32, 1, 0);
-        tqf[0] = trf(qb32, 0, 0);
+        s16x4_t tdl[2], tdh[2], tql[2], tqh[2];
+        trf(qb32, 1, 0, tdl[0], tdh[0]);
+        trf(qb32, 0, 0, tql[0], tqh[0]);
         // dS = P (dP - delta); P and dS are packed to bf16 for BOTH 16-row k-steps before the second phase starts, so that
         // phase holds 16 operand registers instead of the 32 fp32 ones (the register peak of this kernel)
         bf16x8_t pb[2], dsb[2];
@@ -493,13 +527,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv3_kernel(const AttnBwdArgs
           // dS^T[key][query] for the dQ product: this lane's key row, the 16 query rows of k-step s.  A half-wave exchange turns the
           // two 8-byte pieces per lane (rows 16s+4hh.., 16s+8+4hh..) into ONE 16-byte store: lanes 0-31 rows 16s..16s+7, lanes 32-63
           // rows 16s+8..16s+15
-          bf16_t* drow = a.ds + (((int64_t)b * a.H + h) * a.Sp + key) * a.Sp + qt * DKV_QT + qb32 * 32 + 8 * hh;
+          bf16_t* dtile = a.ds + ((int64_t)b * a.H + h) * a.Sp * a.Sp + (int64_t)(my_kt * (a.Sp >> 7) + (qt >> 1)) * (64 * 128);
 #pragma unroll
           for (int s2 = 0; s2 < 2; ++s2) {
             const u32x4_t w = __builtin_bit_cast(u32x4_t, dsb[s2]);
             const auto r0 = __builtin_amdgcn_permlane32_swap(w[0], w[2], false, false);
             const auto r1 = __builtin_amdgcn_permlane32_swap(w[1], w[3], false, false);
-            *reinterpret_cast<u32x4_t*>(drow + 16 * s2) = u32x4_t{r0[0], r1[0], r0[1], r1[1]};
+            const int piece = ((((wave & 1) * 2 + (qt & 1)) * 2 + qb32) * 2 + s2) * 64;  // 64 chunks = 1 KiB per store instruction
+            *reinterpret_cast<u32x4_t*>(dtile + (piece + (int)ln) * 8) = u32x4_t{r0[0], r1[0], r0[1], r1[1]};
           }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -508,11 +543,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv3_kernel(const AttnBwdArgs
 #pragma unroll
         for (int step = 0; step < 8; ++step) {
           if (step + 1 < 8) {
-            td[(step + 1) & 1] = trf(qb32, 1, step + 1);
-            tqf[(step + 1) & 1] = trf(qb32, 0, step + 1);
+            trf(qb32, 1, step + 1, tdl[(step + 1) & 1], tdh[(step + 1) & 1]);
+            trf(qb32, 0, step + 1, tql[(step + 1) & 1], tqh[(step + 1) & 1]);
           }
-          dv[step & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(td[step & 1], pb[step >> 2], dv[step & 3], 0, 0, 0);
-          dk[step & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tqf[step & 1], dsb[step >> 2], dk[step & 3], 0, 0, 0);
+          // this step's 4 reads have landed once all but the next step's 4 are done (LDS returns in order)
+          if (step + 1 < 8) lds_tr_wait4<4>(tdl[step & 1], tdh[step & 1], tql[step & 1], tqh[step & 1]);
+          else lds_tr_wait4<0>(tdl[step & 1], tdh[step & 1], tql[step & 1], tqh[step & 1]);
+          dv[step & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_of(tdl[step & 1], tdh[step & 1]), pb[step >> 2], dv[step & 3], 0, 0, 0);
+          dk[step & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_of(tql[step & 1], tqh[step & 1]), dsb[step >> 2], dk[step & 3], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
         }
         if (qb32 == 0) stamp();  // 6: 16 + 16 MFMAs of the second phase (first 32 rows)
@@ -574,109 +612,189 @@ __global__ __launch_bounds__(256) void attn_bwd_delta_kernel(const AttnBwdArgs a
   }
 }
 
-// dQ^T[d][q] = sum_key K^T[d][key] . dS^T[key][q]: one workgroup = 128 query rows of one head (a wave owns 32), sweeping the key
-// tiles its mask class allows.  Both operands sit in LDS as [key][128] images with the dual-use swizzle and are read TRANSPOSED
-// (ds_read_b64_tr_b16): the contraction index (key) is the image row for both.  K tiles come from L2 (a kv head's K is 1 MB), dS^T
-// tiles stream from HBM exactly once - the kernel is bound by that stream, the MFMA pipe is ~1/4 busy.
-#define DQ2_STAGE_BYTES (2 * TILE_BYTES)
-#define DQ2_LDS_BYTES (3 * DQ2_STAGE_BYTES)
+// dQ^T[d][q] = sum_key K^T[d][key] . dS^T[key][q]: one workgroup = 8 waves = 256 query rows of one head (a wave owns 32), sweeping the
+// key tiles its mask class allows.  Both operands sit in LDS and are read TRANSPOSED (ds_read_b64_tr_b16): the contraction index (key)
+// is the row for both.  Measured on the 128-row predecessor of this kernel (timing probes: no MFMA / LDS reads, every dS^T tile from one
+// address, 2 .. 5 ring stages, one or two workgroups per CU - all within 1 %): the time is the CU's vector-memory delivery, ~24 GB/s per
+// CU for the LDS-DMA fills whatever their source, so the bytes per query row decide: a K tile (16 KiB, from L2) is now shared by 256
+// rows (48 KiB per tile step instead of 64 KiB per 256 rows), the dS^T tiles (2 x 16 KiB, adjacent in the buffer) stream from HBM once.
+#define DQ2_BQ 256
+#define DQ2_STAGE_BYTES (3 * TILE_BYTES)  // K tile + two dS^T tiles
+#define DQ2_STAGES 3
+#define DQ2_LDS_BYTES (DQ2_STAGES * DQ2_STAGE_BYTES)
 
 template <bool GENERAL>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(const AttnBwdArgs a) {
+__global__ __launch_bounds__(512, 2) void attn_bwd_dq2_kernel(const AttnBwdArgs a) {
   extern __shared__ __attribute__((aligned(256))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nqb = (a.S + BQ - 1) / BQ, nkt = (a.S + BKV - 1) / BKV;
-  const int qb = nqb - 1 - blockIdx.y;  // heaviest blocks of every head first
+  const int nqb = (a.S + BQ - 1) / BQ, nkt = (a.S + BKV - 1) / BKV;  // 128-row blocks (the granularity of the tile flags), key tiles
+  const int nqb2 = (a.S + DQ2_BQ - 1) / DQ2_BQ;
+  const int qb2 = nqb2 - 1 - blockIdx.y;  // heaviest blocks of every head first
   const int h = blockIdx.x, b = blockIdx.z;
   const int kvh = h / (a.H / a.KVH);
   const int r = lane & 31, hh = lane >> 5;
-  const int qi = qb * BQ + wave * 32 + r;
+  const int qi = qb2 * DQ2_BQ + wave * 32 + r;
+  const int my_qb = min(2 * qb2 + (wave >> 2), nqb - 1);  // the 128-row block of this wave
 
-  const uint8_t* fl = GENERAL ? a.flags + ((int64_t)b * nqb + qb) * nkt : nullptr;
-  const int kt_end = GENERAL ? nkt : min(nkt, (qb * BQ + BQ + BKV - 1) / BKV);
-  auto tile_class = [&](int t) -> int {
-    if constexpr (GENERAL) return fl[t];
-    else return 1;
-  };
+  const int kt_end = GENERAL ? nkt : min(nkt, (qb2 * DQ2_BQ + DQ2_BQ + BKV - 1) / BKV);
+  // the schedule (tile classes are scalar data): built once, before any LDS-DMA is in flight - a flag load inside the loop would make
+  // the compiler drain the whole LDS-DMA pipeline at every tile.  GENERAL: the non-empty key tiles of the two 128-row blocks as 64-bit
+  // masks in scalar registers (route (a) is taken for up to 128 key tiles); fa = block of waves 0-3, fb = waves 4-7
+  unsigned long long fa0 = 0, fa1 = 0, fb0 = 0, fb1 = 0;
+  if constexpr (GENERAL) {
+    const uint8_t* fla = a.flags + ((int64_t)b * nqb + min(2 * qb2, nqb - 1)) * nkt;
+    const uint8_t* flb = a.flags + ((int64_t)b * nqb + min(2 * qb2 + 1, nqb - 1)) * nkt;
+    const bool has_b = 2 * qb2 + 1 < nqb;
+    fa0 = __builtin_amdgcn_ballot_w64(lane < nkt && fla[min(lane, nkt - 1)] != 0);
+    fa1 = __builtin_amdgcn_ballot_w64(64 + lane < nkt && fla[min(64 + lane, nkt - 1)] != 0);
+    fb0 = __builtin_amdgcn_ballot_w64(has_b && lane < nkt && flb[min(lane, nkt - 1)] != 0);
+    fb1 = __builtin_amdgcn_ballot_w64(has_b && 64 + lane < nkt && flb[min(64 + lane, nkt - 1)] != 0);
+  }
+  const unsigned long long fm0 = fa0 | fb0, fm1 = fa1 | fb1;
   auto next_tile = [&](int t) {
-    while (t < kt_end && tile_class(t) == 0) ++t;
+    if constexpr (GENERAL) {
+      if (t < 64) {
+        const unsigned long long m = fm0 >> t;
+        if (m) return t + (int)__builtin_ctzll(m);
+        t = 64;
+      }
+      if (t < 128) {
+        const unsigned long long m = fm1 >> (t - 64);
+        if (m) return t + (int)__builtin_ctzll(m);
+      }
+      return kt_end;
+    }
     return t;
   };
-  // causal arithmetic: the dK/dV kernel works on 64-row query tiles and never touches (query tile 2qb, key tile 2qb+1), so the first
-  // two waves (query rows 0..63 of the block) must not consume that quadrant of the buffer
-  const int my_last = GENERAL ? nkt : 2 * qb + (wave >> 1);
+  // which staged tiles this wave consumes.  GENERAL: the tiles its own 128-row block has flagged (the dK/dV kernel wrote exactly those).
+  // Causal arithmetic: the dK/dV kernel works on 64-row query tiles and touches (query tile qt, key tile t) for t <= qt only.
+  const unsigned long long my0 = (wave >> 2) ? fb0 : fa0, my1 = (wave >> 2) ? fb1 : fa1;
+  const int my_last = 4 * qb2 + (wave >> 1);
+  auto mine = [&](int t) -> bool {
+    if constexpr (GENERAL) return t < 64 ? ((my0 >> t) & 1) != 0 : ((my1 >> (t - 64)) & 1) != 0;
+    return t <= my_last;
+  };
 
+  // ---- staging: per tile step 6 LDS-DMA loads per thread: K tile = 16 pieces of 1 KiB (4 rows), wave w takes pieces w and w + 8;
+  // the two dS^T tiles = 32 contiguous pieces, wave w takes pieces w, w + 8, w + 16, w + 24 (copied as they lie)
   const int srow_in = lane >> 4, sslot = lane & 15;
   const bf16_t* kbase = a.k + (int64_t)b * a.k_sb + kvh * HD;
-  const bf16_t* dbase = a.ds + ((int64_t)b * a.H + h) * a.Sp * a.Sp + qb * BQ;
-  uint32_t koff[4], doff[4];
+  const bf16_t* dbase = a.ds + ((int64_t)b * a.H + h) * a.Sp * a.Sp + (int64_t)(2 * qb2) * (64 * 128);  // tiles (t, 2qb2), (t, 2qb2+1): 32 KiB
+  const int64_t dtile = (int64_t)(a.Sp >> 7) * (64 * 128);
+  uint32_t koff[2];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = i * 16 + wave * 4 + srow_in;
+  for (int i = 0; i < 2; ++i) {
+    const int row = (i * 8 + wave) * 4 + srow_in;
     koff[i] = (uint32_t)(((int64_t)row * a.k_ss + (sslot ^ dual_swz(row)) * 8) * 2);
-    doff[i] = (uint32_t)(((int64_t)row * a.Sp + (sslot ^ dual_swz(row)) * 8) * 2);
   }
   auto stage = [&](int buf, int t) {
     char* sK = smem + buf * DQ2_STAGE_BYTES;
     char* sD = sK + TILE_BYTES;
-    const char* dt = (const char*)(dbase + (int64_t)t * BKV * a.Sp);  // rows t*64 .. +63 < Sp always
+    const char* dt = (const char*)(dbase + ((a.probe & 1) ? 0 : t) * dtile) + lane * 16;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) __builtin_amdgcn_global_load_lds((gbl_void*)(dt + doff[i]), (lds_void*)(sD + (i * 16 + wave * 4) * 256), 16, 0, 0);
+    for (int i = 0; i < 4; ++i) __builtin_amdgcn_global_load_lds((gbl_void*)(dt + (i * 8 + wave) * 1024), (lds_void*)(sD + (i * 8 + wave) * 1024), 16, 0, 0);
     if (t * BKV + BKV <= a.S) {
       const char* kt = (const char*)(kbase + (int64_t)t * BKV * a.k_ss);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) __builtin_amdgcn_global_load_lds((gbl_void*)(kt + koff[i]), (lds_void*)(sK + (i * 16 + wave * 4) * 256), 16, 0, 0);
+      for (int i = 0; i < 2; ++i) __builtin_amdgcn_global_load_lds((gbl_void*)(kt + koff[i]), (lds_void*)(sK + (i * 8 + wave) * 1024), 16, 0, 0);
     } else {  // ragged last key tile: clamp the row (its dS^T rows are zero)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int row = i * 16 + wave * 4 + srow_in;
+      for (int i = 0; i < 2; ++i) {
+        const int row = (i * 8 + wave) * 4 + srow_in;
         const int key = min(t * BKV + row, a.S - 1);
-        __builtin_amdgcn_global_load_lds((gbl_void*)(kbase + (int64_t)key * a.k_ss + (sslot ^ dual_swz(row)) * 8), (lds_void*)(sK + (i * 16 + wave * 4) * 256), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_void*)(kbase + (int64_t)key * a.k_ss + (sslot ^ dual_swz(row)) * 8), (lds_void*)(sK + (i * 8 + wave) * 1024), 16, 0, 0);
       }
     }
   };
 
+  // lane constants of the transposed reads (element map of tr_frag).  K: byte offset inside the [64][128] dual-use image of the lo / hi
+  // 4-row blocks of k-step 0; k-step ks adds 4096 bytes (the swizzle of a row does not depend on ks).  dS^T: the stage holds the two
+  // tiles in the PRODUCER's chunk order (AttnBwdArgs::ds): chunk(key, q) at 16 x (kh*512 + qh*256 + qb32*128 + s*64 + hh'*32 + r); this
+  // wave's query block fixes the tile (wave>>2) and (qh, qb32) = ((wave>>1)&1, wave&1), the lane's 16-column half s = tsub and 8-column
+  // quarter hh' = tp>>1, its key row r = 16 (ks&1) + 4 hh + tq (+8 for the hi block), kh = ks>>1: k-step offsets {0, 256, 8192, 8448},
+  // hi block +128 (immediates).  (a 32-lane half reads four 64-byte runs 512 bytes apart: 4-way on the banks - 8 of 40 reads per tile)
+  const uint32_t sbase = (uint32_t)(uintptr_t)(lds_char*)smem;
+  uint32_t aK_lo[4], aK_hi[4], aD;
+  {
+    const int tq2 = (lane & 15) >> 2, tp = lane & 3, tsub = (lane >> 4) & 1;
+    const int rlo = 4 * hh + tq2, rhi = rlo + 8;
+    auto off = [&](int row, int blk) { return (uint32_t)(row * 256 + (((4 * blk + 2 * tsub + (tp >> 1)) ^ dual_swz(row)) << 4) + ((tp & 1) << 3)); };
+#pragma unroll
+    for (int db = 0; db < 4; ++db) { aK_lo[db] = off(rlo, db); aK_hi[db] = off(rhi, db); }
+    aD = (uint32_t)(TILE_BYTES + (wave >> 2) * TILE_BYTES + ((wave >> 1) & 1) * 4096 + (wave & 1) * 2048 + tsub * 1024 + (tp >> 1) * 512 + rlo * 16 + (tp & 1) * 8);
+  }
   f32x16_t dq[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int e = 0; e < 16; ++e) dq[i][e] = 0.f;
 
-  // three LDS stages: the tiles t+1 and t+2 are in flight while tile t is consumed (8 loads per thread and tile)
-  int t0 = next_tile(0);
-  int t1 = t0 < kt_end ? next_tile(t0 + 1) : kt_end;
-  if (t0 < kt_end) stage(0, t0);
-  if (t1 < kt_end) stage(1, t1);
+  // three LDS stages: tiles t+1 and t+2 are in flight while tile t is consumed (6 LDS-DMA loads per thread and tile; a counted vmcnt
+  // retires exactly the oldest tile)
+  int tq[DQ2_STAGES];  // tile numbers of the stages in consumption order: tq[0] is consumed next
+  tq[0] = next_tile(0);
+#pragma unroll
+  for (int i = 1; i < DQ2_STAGES; ++i) tq[i] = tq[i - 1] < kt_end ? next_tile(tq[i - 1] + 1) : kt_end;
+#pragma unroll
+  for (int i = 0; i < DQ2_STAGES - 1; ++i)
+    if (tq[i] < kt_end) stage(i, tq[i]);
   int cur = 0;
-  while (t0 < kt_end) {
-    const int t2 = t1 < kt_end ? next_tile(t1 + 1) : kt_end;
-    if (t2 < kt_end) {
-      stage((cur + 2) % 3, t2);
-      asm volatile("s_waitcnt vmcnt(16)" ::: "memory");  // tile t0 has landed; t1 and t2 (8 loads each) stay in flight
-    } else if (t1 < kt_end) {
-      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  while (tq[0] < kt_end) {
+    if (tq[2] < kt_end) {
+      stage((cur + 2) % DQ2_STAGES, tq[2]);
+      asm volatile("s_waitcnt vmcnt(12)" ::: "memory");  // all but the two youngest tiles have landed
+    } else if (tq[1] < kt_end) {
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    const char* sK = smem + cur * DQ2_STAGE_BYTES;
-    const char* sD = sK + TILE_BYTES;
-    if (t0 <= my_last) {
+    if (mine(tq[0]) && !(a.probe & 2)) {
+      // 4 k-steps of 16 keys: the 10 transposed reads (dS^T fragment + 4 K^T fragments, lo / hi halves) of step ks+1 are in flight
+      // while the 4 MFMAs of step ks run
+      const uint32_t so = sbase + cur * DQ2_STAGE_BYTES;
+      s16x4_t Dl[2], Dh[2], Kl[2][4], Kh[2][4];
+      auto reads = [&](auto set_tag, auto ks_tag) {
+        constexpr int st = decltype(set_tag)::value, ks = decltype(ks_tag)::value, off = ks * 4096, doff_ = (ks >> 1) * 8192 + (ks & 1) * 256;
+        lds_tr_read<doff_>(Dl[st], so + aD);
+        lds_tr_read<doff_ + 128>(Dh[st], so + aD);
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const bf16x8_t dsf = tr_frag(sD, 16 * ks, wave, lane);
+        for (int db = 0; db < 4; ++db) {
+          lds_tr_read<off>(Kl[st][db], so + aK_lo[db]);
+          lds_tr_read<off>(Kh[st][db], so + aK_hi[db]);
+        }
+      };
+      auto mfmas = [&](auto set_tag) {
+        constexpr int st = decltype(set_tag)::value;
+        const bf16x8_t dsf = frag_of(Dl[st], Dh[st]);
 #pragma unroll
-        for (int db = 0; db < 4; ++db) dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(sK, 16 * ks, db, lane), dsf, dq[db], 0, 0, 0);
-      }
+        for (int db = 0; db < 4; ++db) dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_of(Kl[st][db], Kh[st][db]), dsf, dq[db], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+      using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+      reads(I0{}, I0{});
+      reads(I1{}, I1{});
+      lds_tr_wait<10>(Dl[0], Dh[0], Kl[0], Kh[0]);
+      mfmas(I0{});
+      reads(I0{}, I2{});
+      lds_tr_wait<10>(Dl[1], Dh[1], Kl[1], Kh[1]);
+      mfmas(I1{});
+      reads(I1{}, I3{});
+      lds_tr_wait<10>(Dl[0], Dh[0], Kl[0], Kh[0]);
+      mfmas(I0{});
+      lds_tr_wait<0>(Dl[1], Dh[1], Kl[1], Kh[1]);
+      mfmas(I1{});
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // every wave is done reading stage `cur`: the next iteration's DMA may overwrite it
     asm volatile("" ::: "memory");
-    cur = (cur + 1) % 3;
-    t0 = t1;
-    t1 = t2;
+    cur = (cur + 1) % DQ2_STAGES;
+    tq[0] = tq[1];
+    tq[1] = tq[2];
+    tq[2] = tq[1] < kt_end ? next_tile(tq[1] + 1) : kt_end;
   }
 
   if (qi < a.S) {
@@ -743,9 +861,9 @@ extern "C" int64_t llx_attn_bwd_workspace_bytes(int64_t B, int64_t S, int64_t H,
   return (2 * B * H * S + (H / KVH) * 2 * B * S * KVH * HD) * 4;
 }
 
-// bf16 dS^T buffer of route (a): [B][H][Sp][Sp] with Sp = S rounded up to 128 (only the tiles the mask allows are written and read).
+// bf16 dS^T buffer of route (a): [B][H][Sp][Sp] with Sp = S rounded up to 256 (only the tiles the mask allows are written and read).
 extern "C" int64_t llx_attn_bwd_ds_bytes(int64_t B, int64_t S, int64_t H) {
-  const int64_t Sp = cdiv64(S, 128) * 128;
+  const int64_t Sp = cdiv64(S, 256) * 256;
   return B * H * Sp * Sp * 2;
 }
 
@@ -796,14 +914,16 @@ extern "C" int llx_attn_bwd(const void* q, int64_t q_sb, int64_t q_ss, const voi
   AttnBwdArgs a;
   a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.o = (const bf16_t*)o; a.d_o = (const bf16_t*)d_o;
   a.lse = lse; a.delta = delta; a.nlse = delta + B * H * S; a.stamps = nullptr; a.rope = rope; a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk; a.dv = (bf16_t*)dv;
-  a.ds = (bf16_t*)ds; a.Sp = (int)(cdiv64(S, 128) * 128);
+  a.ds = (bf16_t*)ds; a.Sp = (int)(cdiv64(S, 256) * 256);
+  { static int probe = -1; if (probe < 0) { const char* e = getenv("LLX_DQ2_PROBE"); probe = e ? atoi(e) : 0; } a.probe = probe; }
   a.q_sb = q_sb; a.q_ss = q_ss; a.k_sb = k_sb; a.k_ss = k_ss; a.v_sb = v_sb; a.v_ss = v_ss; a.o_sb = o_sb; a.o_ss = o_ss;
   a.do_sb = do_sb; a.do_ss = do_ss; a.dq_sb = dq_sb; a.dq_ss = dq_ss; a.dk_sb = dk_sb; a.dk_ss = dk_ss; a.dv_sb = dv_sb; a.dv_ss = dv_ss;
   a.doc_ids = doc_ids; a.prefix_len = prefix_len; a.flags = (doc_ids || prefix_len) ? (const uint8_t*)flags : nullptr;
   a.B = (int)B; a.S = (int)S; a.H = (int)H; a.KVH = (int)KVH;
   a.scale = scale; a.scale_log2 = scale * 1.4426950408889634f;
   const dim3 qgrid((unsigned)H, (unsigned)cdiv64(S, BQ), (unsigned)B);
-  const bool use_ds = ds != nullptr && !g_bwd_stamps;
+  // (with tile flags the dQ-from-dS kernel keeps its schedule in two 64-bit masks: up to 128 key tiles = 8192 positions)
+  const bool use_ds = ds != nullptr && !g_bwd_stamps && !((doc_ids || prefix_len) && cdiv64(S, BKV) > 128);
   if (use_ds) {
     hipLaunchKernelGGL(attn_bwd_delta_kernel, dim3((unsigned)cdiv64(B * S * H, 16)), dim3(256), 0, stream, a);
     LLX_LAUNCH_CHECK("llx_attn_bwd(delta)");
@@ -829,8 +949,9 @@ extern "C" int llx_attn_bwd(const void* q, int64_t q_sb, int64_t q_ss, const voi
   hipLaunchKernelGGL(attn_dkv_reduce_kernel, dim3((unsigned)cdiv64(plane / 8, 256)), dim3(256), 0, stream, a, (const float*)part);
   LLX_LAUNCH_CHECK("llx_attn_bwd(dkv reduce)");
   if (use_ds) {
-    if (a.flags) hipLaunchKernelGGL(attn_bwd_dq2_kernel<true>, qgrid, dim3(256), DQ2_LDS_BYTES, stream, a);
-    else hipLaunchKernelGGL(attn_bwd_dq2_kernel<false>, qgrid, dim3(256), DQ2_LDS_BYTES, stream, a);
+    const dim3 q2grid((unsigned)H, (unsigned)cdiv64(S, DQ2_BQ), (unsigned)B);
+    if (a.flags) hipLaunchKernelGGL(attn_bwd_dq2_kernel<true>, q2grid, dim3(512), DQ2_LDS_BYTES, stream, a);
+    else hipLaunchKernelGGL(attn_bwd_dq2_kernel<false>, q2grid, dim3(512), DQ2_LDS_BYTES, stream, a);
     LLX_LAUNCH_CHECK("llx_attn_bwd(dq from dS)");
   }
   return LLX_OK;

@@ -16,6 +16,8 @@
 // K/V tiles are double-buffered in LDS by global_load_lds with the bank swizzle applied on the source address.
 #include "common.h"
 #include <stdlib.h>
+#include <mutex>
+#include <type_traits>
 
 #define HD 128
 #define BQ 128
@@ -122,9 +124,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnFwdArgs a) {
   const int my_doc = docrow ? docrow[qrow] : 0;
   const int my_prefix = (GENERAL && a.prefix_len) ? a.prefix_len[b] : 0;
 
-  // tr-read lane constants: group-local i = lane&15 -> q4 = i>>2 (row in block), p = i&3
+  // tr-read lane constants: group-local i = lane&15 -> q4 = i>>2 (row in block), p = i&3.  aV[db] = byte offset inside the V image of
+  // this lane's lo 4-row block of k-step 0 for d-block db: row 4hh + tq, chunk (4db + 2tsub + (tp>>1)) ^ (tq << 2) (the V image's
+  // swizzle; (row & 3) == tq for every block), 8-byte half tp & 1.  Step (kb, s) adds 4096 bytes, the hi block 2048.
   const int tq = (lane & 15) >> 2, tp = lane & 3;
   const int tsub = (lane >> 4) & 1;
+  const uint32_t sbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  uint32_t aV[4];
+#pragma unroll
+  for (int db = 0; db < 4; ++db) aV[db] = (uint32_t)((4 * hh + tq) * 256 + (((4 * db + 2 * tsub + (tp >> 1)) ^ (tq << 2)) << 4) + ((tp & 1) << 3));
 
   int t = next_tile(0);
   if (t < kt_end) stage(0, t);
@@ -216,28 +224,42 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnFwdArgs a) {
     m_run = m_new;
 
     stamp();  // 2: after softmax
-    // ---- O^T += V^T.P^T : P^T k-step (kb, s) = accumulator regs 8s..8s+7; element j <-> key 32kb+16s+8(j>>2)+4hh+(j&3)
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        bf16x8_t pb;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) pb[j] = (__bf16)st[kb][8 * s + j];
-        const int key0 = kb * 32 + s * 16 + 4 * hh;
+    // ---- O^T += V^T.P^T : P^T k-step (kb, s) = accumulator regs 8s..8s+7; element j <-> key 32kb+16s+8(j>>2)+4hh+(j&3).
+    // V^T fragments by transposed reads issued as inline asm (common.h: lds_tr_read - the builtin form would drain the K/V prefetch
+    // of the next tile right here): the 8 reads of step i+1 are in flight while the 4 MFMAs of step i run.
+    {
+      const uint32_t vb = sbase + cur * ATT_STAGE_BYTES + KV_TILE_BYTES;
+      s16x4_t Vl[2][4], Vh[2][4];
+      auto reads = [&](auto set_tag, auto step_tag) {
+        constexpr int st_ = decltype(set_tag)::value, off = decltype(step_tag)::value * 4096;  // step = (kb, s): 16 keys = 4096 bytes
 #pragma unroll
         for (int db = 0; db < 4; ++db) {
-          const int chunk = 4 * db + 2 * tsub + (tp >> 1);
-          const int row_lo = key0 + tq, row_hi = key0 + 8 + tq;
-          // (row & 3) == tq for both rows (key0 and key0+8 are multiples of 4)
-          const int off = (((chunk ^ (tq << 2)) << 4) | ((tp & 1) << 3));
-          s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(sV + row_lo * 256 + off));
-          s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(sV + row_hi * 256 + off));
-          typedef __attribute__((ext_vector_type(8))) short s16x8_t;
-          s16x8_t vv = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-          o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, vv), pb, o[db], 0, 0, 0);
+          lds_tr_read<off>(Vl[st_][db], vb + aV[db]);
+          lds_tr_read<off + 2048>(Vh[st_][db], vb + aV[db]);  // the hi block: 8 rows further
         }
-      }
+      };
+      auto pv = [&](auto set_tag, auto step_tag) {
+        constexpr int st_ = decltype(set_tag)::value, step = decltype(step_tag)::value;
+        bf16x8_t pb;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pb[j] = (__bf16)st[step >> 1][8 * (step & 1) + j];
+        if constexpr (step < 3) lds_tr_wait8<8>(Vl[st_], Vh[st_]);
+        else lds_tr_wait8<0>(Vl[st_], Vh[st_]);
+#pragma unroll
+        for (int db = 0; db < 4; ++db) o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_of(Vl[st_][db], Vh[st_][db]), pb, o[db], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+      using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+      reads(I0{}, I0{});
+      reads(I1{}, I1{});
+      pv(I0{}, I0{});
+      reads(I0{}, I2{});
+      pv(I1{}, I1{});
+      reads(I1{}, I3{});
+      pv(I0{}, I2{});
+      pv(I1{}, I3{});
+    }
 
     stamp();  // 3: after PV
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -286,7 +308,6 @@ __global__ void attn_tile_flags_kernel(const int* __restrict__ doc_ids, const in
   if (threadIdx.x == 0) flags[((int64_t)b * nqb + qb) * nkt + kt] = s_any ? (s_all ? 2 : 1) : 0;
 }
 
-static bool g_attn_attr = false;
 
 extern "C" int64_t llx_attn_flags_bytes(int64_t B, int64_t S) { return B * cdiv64(S, BQ) * cdiv64(S, BKV); }
 
@@ -312,11 +333,14 @@ extern "C" int llx_attn_fwd(const void* q, int64_t q_sb, int64_t q_ss, const voi
   LLX_REQUIRE(((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) % 16 == 0 && (uintptr_t)o % 8 == 0, "llx_attn_fwd: unaligned pointer");
   LLX_REQUIRE(!(doc_ids || prefix_len) || flags, "llx_attn_fwd: tile flags required with doc_ids/prefix_len");
   LLX_REQUIRE(S < (1 << 24), "llx_attn_fwd: S too large");
-  if (!g_attn_attr) {
-    hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS_BYTES);
-    hipError_t e2 = hipFuncSetAttribute((const void*)attn_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS_BYTES);
-    if (e != hipSuccess || e2 != hipSuccess) { llx_set_error("llx_attn_fwd: %s", hipGetErrorString(e != hipSuccess ? e : e2)); return LLX_ERR_LAUNCH; }
-    g_attn_attr = true;
+  {
+    static std::once_flag once;  // forward may be entered from several host threads (activation checkpointing recomputes it in backward)
+    static hipError_t err = hipSuccess;
+    std::call_once(once, [] {
+      err = hipFuncSetAttribute((const void*)attn_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS_BYTES);
+      if (err == hipSuccess) err = hipFuncSetAttribute((const void*)attn_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS_BYTES);
+    });
+    if (err != hipSuccess) { llx_set_error("llx_attn_fwd: %s", hipGetErrorString(err)); return LLX_ERR_LAUNCH; }
   }
   AttnFwdArgs a;
   a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.o = (bf16_t*)o; a.lse = lse;

@@ -152,3 +152,33 @@ __device__ __forceinline__ u32x4_t rope8(const u32x4_t& v, const float* __restri
   }
   return o;
 }
+
+// ---- ds_read_b64_tr_b16 as inline asm.  Through the builtin hipcc treats the transposed read as an LDS access it cannot order against
+// the LDS-DMA writes in flight and puts `s_waitcnt vmcnt(0)` in front of it: every prefetched tile is drained before the first
+// transposed read of a tile (seen in the .s of the attention kernels; it made the four-stage ring of the dQ-from-dS kernel synchronous,
+// 1.7 us per tile, and cut the forward kernel's K/V prefetch off before its PV phase).  As asm the read is invisible to that pass;
+// ordering is by hand: the issuing wave's counted vmcnt + barrier before the read (LDS-DMA RAW), an lgkmcnt wait that names every
+// destination "+v" (so no consumer can be scheduled above it) followed by sched_barrier(0) before the first use.
+typedef __attribute__((ext_vector_type(8))) short llx_s16x8_t;
+template <int OFF>
+__device__ __forceinline__ void lds_tr_read(s16x4_t& dst, uint32_t addr) {
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
+// the same with the offset as a (constant after unrolling) function argument
+__device__ __forceinline__ void lds_tr_read_rt(s16x4_t& dst, uint32_t addr, int off) {
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off));
+}
+template <int N>
+__device__ __forceinline__ void lds_tr_wait4(s16x4_t& a, s16x4_t& b, s16x4_t& c, s16x4_t& d) {
+  asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N));
+  __builtin_amdgcn_sched_barrier(0);
+}
+template <int N>
+__device__ __forceinline__ void lds_tr_wait8(s16x4_t (&c)[4], s16x4_t (&d)[4]) {
+  asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]) : "n"(N));
+  __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ bf16x8_t frag_of(const s16x4_t& lo, const s16x4_t& hi) {
+  const llx_s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8_t, v);
+}

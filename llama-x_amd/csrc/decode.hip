@@ -51,11 +51,49 @@ __device__ __forceinline__ float dot8(const u32x4_t& w, const float (&xf)[8]) {
 template <int MT, int EPI, bool NORM>
 __global__ __launch_bounds__(256, 2) void gemv_kernel(const GemvArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  bf16_t* xs = reinterpret_cast<bf16_t*>(smem);  // [MT][K]
-  float* red = reinterpret_cast<float*>(smem + (size_t)MT * a.K * 2);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int K = a.K;
+  const int nsteps = (K + 1023) >> 10;  // a step = two 512-element pieces (64 lanes x 8) of four weight rows: 8 x 16-byte loads per lane
+  const int Kp = nsteps << 10;          // the LDS copy of x is zero-padded to whole steps: weight lanes past K multiply zeros
+  bf16_t* xs = reinterpret_cast<bf16_t*>(smem);  // [MT][Kp]
+  float* red = reinterpret_cast<float*>(smem + (size_t)MT * Kp * 2);
+
+  // ---- row groups: 4 output rows per wave at a time.  SWIGLU: the gate and up rows of two hidden units (W[0] rows 2g, 2g+1 and
+  // W[1] rows 2g, 2g+1), so that the epilogue has g and u of one unit side by side.
+  struct Grp { const bf16_t* wr[4]; int row0, seg; };
+  auto setup = [&](int g, Grp& G) {
+    if constexpr (EPI == GV_SWIGLU) {
+      const int half = a.N / 2;
+      G.row0 = 2 * g; G.seg = 0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) G.wr[r] = a.W[r >> 1] + (int64_t)min(G.row0 + (r & 1), half - 1) * a.ldw[r >> 1];
+    } else {
+      G.row0 = 4 * g;
+      G.seg = G.row0 >= a.seg_end[0] ? (G.row0 >= a.seg_end[1] ? 2 : 1) : 0;  // wave-uniform (segment boundaries are multiples of 4)
+      const int base = G.seg == 0 ? 0 : a.seg_end[G.seg - 1];
+      const int last = a.seg_end[G.seg] - 1 - base;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) G.wr[r] = a.W[G.seg] + (int64_t)min(G.row0 - base + r, last) * a.ldw[G.seg];
+    }
+  };
+  auto load_step = [&](u32x4_t (&w)[8], const Grp& G, int s) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int k = (2 * s + j) * 512 + lane * 8;
+      const int kk = k < K ? k : 0;  // lanes past the row end re-read its start; their x is zero
+#pragma unroll
+      for (int r = 0; r < 4; ++r) w[4 * j + r] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(G.wr[r] + kk));
+    }
+  };
+  const int nwaves = gridDim.x * 4;
+  const int ngroups = EPI == GV_SWIGLU ? (a.N / 2 + 1) / 2 : (a.N + 3) / 4;
+  int g = blockIdx.x * 4 + wave, s = 0;
+  Grp cur, nxt;
+  u32x4_t WA[8], WB[8];
+  // the first weight loads do not depend on x: they fly while the activation rows are staged (and normalised)
+  if (g < ngroups) { setup(g, cur); load_step(WA, cur, 0); }
+
   // ---- the activation rows into LDS (normalised on the way when NORM)
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
@@ -71,85 +109,43 @@ __global__ __launch_bounds__(256, 2) void gemv_kernel(const GemvArgs a) {
       ss = block_sum(ss, red);
       rstd = rsqrtf(ss / (float)K + a.eps);
     }
-    for (int i = tid * 8; i < K; i += 2048) {
-      u32x4_t v = *reinterpret_cast<const u32x4_t*>(xr + i);
-      if constexpr (NORM) {
-        const u32x4_t w = *reinterpret_cast<const u32x4_t*>(a.norm_w + i);
+    for (int i = tid * 8; i < Kp; i += 2048) {
+      u32x4_t v = {0u, 0u, 0u, 0u};
+      if (i < K) {
+        v = *reinterpret_cast<const u32x4_t*>(xr + i);
+        if constexpr (NORM) {
+          const u32x4_t w = *reinterpret_cast<const u32x4_t*>(a.norm_w + i);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = pack_bf2(bflo(v[e]) * rstd * bflo(w[e]), bfhi(v[e]) * rstd * bfhi(w[e]));
+          for (int e = 0; e < 4; ++e) v[e] = pack_bf2(bflo(v[e]) * rstd * bflo(w[e]), bfhi(v[e]) * rstd * bfhi(w[e]));
+        }
       }
-      *reinterpret_cast<u32x4_t*>(xs + (size_t)m * K + i) = v;
+      *reinterpret_cast<u32x4_t*>(xs + (size_t)m * Kp + i) = v;
     }
   }
   __syncthreads();
 
-  // ---- row groups: 4 output rows per wave at a time.  SWIGLU: the gate and up rows of two hidden units (W[0] rows 2g, 2g+1 and
-  // W[1] rows 2g, 2g+1), so that the epilogue has g and u of one unit side by side.
-  const int nwaves = gridDim.x * 4;
-  const int ngroups = EPI == GV_SWIGLU ? (a.N / 2 + 1) / 2 : (a.N + 3) / 4;
-  const int nfull = K / 512;            // whole 512-element pieces (64 lanes x 8)
-  const bool tail = (K & 511) != 0;     // a last, partly filled piece (K % 8 == 0)
-  const bool tail_on = nfull * 512 + lane * 8 < K;
-  for (int g = blockIdx.x * 4 + wave; g < ngroups; g += nwaves) {
-    const bf16_t* wr[4];
-    int row0 = 0, seg = 0;
-    if constexpr (EPI == GV_SWIGLU) {
-      const int half = a.N / 2;
-      row0 = 2 * g;
+  float acc[4][MT];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) wr[r] = a.W[r >> 1] + (int64_t)min(row0 + (r & 1), half - 1) * a.ldw[r >> 1];
-    } else {
-      row0 = 4 * g;
-      seg = row0 >= a.seg_end[0] ? (row0 >= a.seg_end[1] ? 2 : 1) : 0;  // wave-uniform (segment boundaries are multiples of 4)
-      const int base = seg == 0 ? 0 : a.seg_end[seg - 1];
-      const int last = a.seg_end[seg] - 1 - base;
+  for (int r = 0; r < 4; ++r)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) wr[r] = a.W[seg] + (int64_t)min(row0 - base + r, last) * a.ldw[seg];
-    }
-    float acc[4][MT];
+    for (int m = 0; m < MT; ++m) acc[r][m] = 0.f;
+  auto compute_step = [&](const u32x4_t (&w)[8], int st) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-      for (int m = 0; m < MT; ++m) acc[r][m] = 0.f;
-    auto piece = [&](const u32x4_t (&w)[4], int k) {
+    for (int j = 0; j < 2; ++j) {
+      const int k = (2 * st + j) * 512 + lane * 8;
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
-        const u32x4_t xv = *reinterpret_cast<const u32x4_t*>(xs + (size_t)m * K + k);
+        const u32x4_t xv = *reinterpret_cast<const u32x4_t*>(xs + (size_t)m * Kp + k);
         float xf[8];
 #pragma unroll
         for (int e = 0; e < 4; ++e) { xf[2 * e] = bflo(xv[e]); xf[2 * e + 1] = bfhi(xv[e]); }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[r][m] += dot8(w[r], xf);
+        for (int r = 0; r < 4; ++r) acc[r][m] += dot8(w[4 * j + r], xf);
       }
-    };
-    int c = 0;
-    for (; c + 2 <= nfull; c += 2) {  // 8 x 16-byte loads in flight per lane
-      u32x4_t w0[4], w1[4];
-      const int k0 = c * 512 + lane * 8, k1 = k0 + 512;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) w0[r] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(wr[r] + k0));
-#pragma unroll
-      for (int r = 0; r < 4; ++r) w1[r] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(wr[r] + k1));
-      piece(w0, k0);
-      piece(w1, k1);
     }
-    if (c < nfull) {
-      u32x4_t w0[4];
-      const int k0 = c * 512 + lane * 8;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) w0[r] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(wr[r] + k0));
-      piece(w0, k0);
-    }
-    if (tail) {
-      u32x4_t w0[4];
-      const int k0 = tail_on ? nfull * 512 + lane * 8 : 0;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        w0[r] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(wr[r] + k0));
-        if (!tail_on) w0[r] = u32x4_t{0u, 0u, 0u, 0u};
-      }
-      piece(w0, k0);
-    }
+  };
+  auto finish = [&](const Grp& G) {
+    const int row0 = G.row0, seg = G.seg;
     // LoRA extension: lanes 0 .. rank/8-1 hold 8 elements of the row's B factor each
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -183,10 +179,10 @@ __global__ __launch_bounds__(256, 2) void gemv_kernel(const GemvArgs a) {
       float v[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float s = acc[r][0];
+        float sm = acc[r][0];
 #pragma unroll
-        for (int m = 1; m < MT; ++m) s = lane == m ? acc[r][m] : s;
-        v[r] = bf2f(f2bf(s));  // the linear's bf16 output
+        for (int m = 1; m < MT; ++m) sm = lane == m ? acc[r][m] : sm;
+        v[r] = bf2f(f2bf(sm));  // the linear's bf16 output
       }
       const int m = lane;
       if constexpr (EPI == GV_SWIGLU) {
@@ -195,8 +191,8 @@ __global__ __launch_bounds__(256, 2) void gemv_kernel(const GemvArgs a) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           const float gg = v[j], uu = v[2 + j];
-          const float s = bf2f(f2bf(gg * sigmoidf_(gg)));
-          if (row0 + j < half) a.out[(int64_t)m * a.ldo + row0 + j] = f2bf(s * uu);
+          const float sg = bf2f(f2bf(gg * sigmoidf_(gg)));
+          if (row0 + j < half) a.out[(int64_t)m * a.ldo + row0 + j] = f2bf(sg * uu);
         }
       } else if constexpr (EPI == GV_QKV) {
         // apply_rope on q and k (modelling/llama.py:63-73,122-123; the table row is the token's index IN THIS CALL, :207), then
@@ -229,6 +225,35 @@ __global__ __launch_bounds__(256, 2) void gemv_kernel(const GemvArgs a) {
           }
         }
       }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int m = 0; m < MT; ++m) acc[r][m] = 0.f;
+  };
+  // software pipeline over the flattened (row group, step) sequence of this wave: while one register set is consumed the next step's
+  // 8 loads (of this group or of the wave's next group) are in flight
+  auto body = [&](const u32x4_t (&wc)[8], u32x4_t (&wn)[8]) -> bool {
+    int g2 = g, s2 = s + 1;
+    bool newg = false;
+    if (s2 == nsteps) { g2 = g + nwaves; s2 = 0; newg = true; }
+    const bool has2 = g2 < ngroups;
+    if (has2) {
+      if (newg) { setup(g2, nxt); load_step(wn, nxt, s2); }
+      else load_step(wn, cur, s2);
+    }
+    compute_step(wc, s);
+    if (newg) {
+      finish(cur);
+      cur = nxt;
+    }
+    g = g2; s = s2;
+    return has2;
+  };
+  if (g < ngroups) {
+    while (true) {
+      if (!body(WA, WB)) break;
+      if (!body(WB, WA)) break;
     }
   }
 }
@@ -304,14 +329,31 @@ extern "C" int llx_gemv_bf16(const void* w0, int64_t ldw0, int64_t n0, const voi
   // 2 workgroups of 4 waves per CU; the wave count is trimmed so that every wave gets the same number of row groups where possible
   const int64_t per_wave = cdiv64(groups, 2048);
   const int grid = (int)cdiv64(cdiv64(groups, per_wave), 4);
-  const int MT = M == 1 ? 1 : (M == 2 ? 2 : 4);  // the kernel build stages MT rows (row M-1 repeated)
-  const size_t lds = (size_t)MT * K * 2 + 64;
-  LLX_REQUIRE(lds <= 64 * 1024, "llx_gemv_bf16: M * K too large for the LDS stage");
-  switch (M) {
-    case 1: return launch_gemv_m<1>(a, epilogue, grid, lds, stream);
-    case 2: return launch_gemv_m<2>(a, epilogue, grid, lds, stream);
-    default: return launch_gemv_m<4>(a, epilogue, grid, lds, stream);
+  const int64_t Kp = cdiv64(K, 1024) * 1024;
+  // the build for m rows stages MT = 1 | 2 | 4 rows of x in LDS; above 64 KiB the rows go in pairs (two passes over the weights)
+  auto run = [&](int m0, int mc) -> int {
+    GemvArgs b = a;
+    b.M = mc;
+    b.x = a.x + (int64_t)m0 * a.ldx;
+    b.out = a.out + (int64_t)m0 * a.ldo;
+    if (a.res) b.res = a.res + (int64_t)m0 * a.ldr;
+    if (a.rope) b.rope = a.rope + (int64_t)m0 * 128;
+    if (a.pos) b.pos = a.pos + m0;
+    if (a.t) b.t = a.t + (int64_t)m0 * a.ldt;
+    const int MT = mc == 1 ? 1 : (mc == 2 ? 2 : 4);
+    const size_t lds = (size_t)MT * Kp * 2 + 64;
+    switch (MT) {
+      case 1: return launch_gemv_m<1>(b, epilogue, grid, lds, stream);
+      case 2: return launch_gemv_m<2>(b, epilogue, grid, lds, stream);
+      default: return launch_gemv_m<4>(b, epilogue, grid, lds, stream);
+    }
+  };
+  if (M > 2 && 4 * Kp * 2 + 64 > 64 * 1024) {
+    const int rc = run(0, 2);
+    return rc != LLX_OK ? rc : run(2, (int)M - 2);
   }
+  LLX_REQUIRE((M > 2 ? 4 : M) * Kp * 2 + 64 <= 64 * 1024, "llx_gemv_bf16: M * K too large for the LDS stage");
+  return run(0, (int)M);
 }
 
 // ------------------------------------------------------------------------------------------------- mask extent / cache scatter
@@ -374,16 +416,19 @@ struct DecodeArgs {
   const bf16_t* kc; const bf16_t* vc; int64_t c_sb, c_sh, c_ss;
   const uint8_t* mask; int64_t m_sb, m_sh, m_sq;         // bool [.., M, Skv], broadcast strides, last dim dense
   const int* extent;                                     // nullable: keys >= *extent are masked for every row
-  float* part;                                           // [B, H, M, nsplit * 4, DEC_PART]
+  float* part;                                           // [B, H, M, nsplit, DEC_PART]
   int B, H, KVH, M, Skv, nsplit;
   float scale_log2;
 };
 
 // One workgroup = 4 waves = one key range of one (batch, kv head); ROWS = G * M query rows (the G heads of the group x the tokens of
-// the call) share every K / V row read.  A 16-lane group owns one key per step (lane = 16-byte chunk of the 256-byte row), four keys
-// per wave-instruction, sixteen per workgroup step.
-template <int ROWS>
+// the call) share every K / V row read.  A 16-lane group owns one key per load (lane = 16-byte chunk of the 256-byte row): four keys
+// per wave-instruction, sixteen per wave and step (8 x 16-byte loads in flight per lane), 64 per workgroup step.
+// DEC_KPG = keys per lane group and step: 4 for up to 4 query rows (the batch-1 decode step), fewer for more rows (register budget)
+template <int ROWS, int DEC_KPG>
 __global__ __launch_bounds__(256) void attn_decode_kernel(const DecodeArgs a) {
+  __shared__ float sm_o[4][ROWS][HD];
+  __shared__ float sm_ml[4][ROWS][2];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int split = blockIdx.x, kvh = blockIdx.y, b = blockIdx.z;
@@ -411,20 +456,34 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const DecodeArgs a) {
   }
   const bf16_t* kb = a.kc + b * a.c_sb + kvh * a.c_sh + c * 8;
   const bf16_t* vb = a.vc + b * a.c_sb + kvh * a.c_sh + c * 8;
-  // two keys per lane group and iteration (8 keys per wave, 32 per workgroup): 4 x 16-byte loads in flight per lane
-  for (int k0 = k_lo + wave * 8; k0 < k_hi; k0 += 32) {
-    u32x4_t kv[2], vv[2];
-    int key[2];
+  const bool shared_mask = a.m_sh == 0;  // the reference's mask (tril rows gathered at input_pos) is the same for every head
+  const uint8_t* mbase = a.mask + b * a.m_sb;
+  for (int k0 = k_lo + wave * (4 * DEC_KPG); k0 < k_hi; k0 += 16 * DEC_KPG) {
+    u32x4_t kv[DEC_KPG], vv[DEC_KPG];
+    uint32_t allow[DEC_KPG];  // bit r: query row r may attend to key j
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      key[j] = k0 + j * 4 + grp;
-      const int kk = min(key[j], a.Skv - 1);
+    for (int j = 0; j < DEC_KPG; ++j) {
+      const int key = k0 + j * 4 + grp;
+      const int kk = min(key, a.Skv - 1);
       kv[j] = *reinterpret_cast<const u32x4_t*>(kb + (int64_t)kk * a.c_ss);
       vv[j] = *reinterpret_cast<const u32x4_t*>(vb + (int64_t)kk * a.c_ss);
-    }
-    float s[2][ROWS];
+      uint32_t w = 0;
+      if (shared_mask) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+        for (int m = 0; m < ROWS; ++m)
+          if (m < a.M && mbase[(int64_t)m * a.m_sq + kk] != 0) w |= 1u << m;  // expanded to the G heads below
+      } else {
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+          const int g = r / a.M, m = r % a.M;
+          if (g < G && mbase[(kvh * G + g) * a.m_sh + (int64_t)m * a.m_sq + kk] != 0) w |= 1u << r;
+        }
+      }
+      allow[j] = key < k_hi ? w : 0u;
+    }
+    float s[DEC_KPG][ROWS];
+#pragma unroll
+    for (int j = 0; j < DEC_KPG; ++j) {
       float kf[8];
 #pragma unroll
       for (int e = 0; e < 4; ++e) { kf[2 * e] = bflo(kv[j][e]); kf[2 * e + 1] = bfhi(kv[j][e]); }
@@ -437,28 +496,33 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const DecodeArgs a) {
         d += __shfl_xor(d, 2, 64);
         d += __shfl_xor(d, 4, 64);
         d += __shfl_xor(d, 8, 64);
-        const int g = r / a.M, m = r % a.M;
-        const int h = kvh * G + min(g, G - 1);
-        const bool ok = key[j] < k_hi && a.mask[b * a.m_sb + h * a.m_sh + (int64_t)m * a.m_sq + min(key[j], a.Skv - 1)] != 0;
+        const bool ok = shared_mask ? ((allow[j] >> (r % a.M)) & 1u) != 0 : ((allow[j] >> r) & 1u) != 0;
         s[j][r] = ok ? d : -INFINITY;
       }
     }
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) {
-      const float mn = fmaxf(mx[r], fmaxf(s[0][r], s[1][r]));
+      float mn = mx[r];
+#pragma unroll
+      for (int j = 0; j < DEC_KPG; ++j) mn = fmaxf(mn, s[j][r]);
       if (mn == -INFINITY) continue;  // nothing to attend to so far for this row in this lane group
       const float alpha = __builtin_amdgcn_exp2f(mx[r] - mn);
-      const float p0 = __builtin_amdgcn_exp2f(s[0][r] - mn), p1 = __builtin_amdgcn_exp2f(s[1][r] - mn);
-      ls[r] = ls[r] * alpha + p0 + p1;
+      float p[DEC_KPG], psum = 0.f;
+#pragma unroll
+      for (int j = 0; j < DEC_KPG; ++j) { p[j] = __builtin_amdgcn_exp2f(s[j][r] - mn); psum += p[j]; }
+      ls[r] = ls[r] * alpha + psum;
       mx[r] = mn;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        o[r][2 * e] = o[r][2 * e] * alpha + p0 * bflo(vv[0][e]) + p1 * bflo(vv[1][e]);
-        o[r][2 * e + 1] = o[r][2 * e + 1] * alpha + p0 * bfhi(vv[0][e]) + p1 * bfhi(vv[1][e]);
+        float lo = o[r][2 * e] * alpha, hi = o[r][2 * e + 1] * alpha;
+#pragma unroll
+        for (int j = 0; j < DEC_KPG; ++j) { lo = __builtin_fmaf(p[j], bflo(vv[j][e]), lo); hi = __builtin_fmaf(p[j], bfhi(vv[j][e]), hi); }
+        o[r][2 * e] = lo; o[r][2 * e + 1] = hi;
       }
     }
   }
-  // merge the four lane groups of the wave (lanes l, l^16, l^32, l^48 hold the same dims of different keys)
+  // merge the four lane groups of the wave (lanes l, l^16, l^32, l^48 hold the same dims of different keys), then the four waves
+  // through LDS: ONE partial (m, l, o) per workgroup and query row
 #pragma unroll
   for (int r = 0; r < ROWS; ++r) {
 #pragma unroll
@@ -471,37 +535,55 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const DecodeArgs a) {
       for (int e = 0; e < 8; ++e) o[r][e] = o[r][e] * fa + __shfl_xor(o[r][e], off, 64) * fb;
       mx[r] = mn;
     }
-    const int g = r / a.M, m = r % a.M;
-    if (grp == 0 && g < G) {
-      const int h = kvh * G + g;
-      float* pp = a.part + ((((int64_t)b * a.H + h) * a.M + m) * (a.nsplit * 4) + split * 4 + wave) * DEC_PART;
-      *reinterpret_cast<f32x4_t*>(pp + c * 8) = f32x4_t{o[r][0], o[r][1], o[r][2], o[r][3]};
-      *reinterpret_cast<f32x4_t*>(pp + c * 8 + 4) = f32x4_t{o[r][4], o[r][5], o[r][6], o[r][7]};
-      if (c == 0) { pp[128] = mx[r]; pp[129] = ls[r]; }
+    if (grp == 0) {
+      *reinterpret_cast<f32x4_t*>(&sm_o[wave][r][c * 8]) = f32x4_t{o[r][0], o[r][1], o[r][2], o[r][3]};
+      *reinterpret_cast<f32x4_t*>(&sm_o[wave][r][c * 8 + 4]) = f32x4_t{o[r][4], o[r][5], o[r][6], o[r][7]};
+      if (c == 0) { sm_ml[wave][r][0] = mx[r]; sm_ml[wave][r][1] = ls[r]; }
     }
+  }
+  __syncthreads();
+  for (int idx = tid; idx < ROWS * HD; idx += 256) {
+    const int r = idx >> 7, d = idx & (HD - 1);
+    const int g = r / a.M, m = r % a.M;
+    if (g >= G) continue;
+    float mm = fmaxf(fmaxf(sm_ml[0][r][0], sm_ml[1][r][0]), fmaxf(sm_ml[2][r][0], sm_ml[3][r][0]));
+    float num = 0.f, den = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float f = sm_ml[w][r][0] == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(sm_ml[w][r][0] - mm);
+      num += sm_o[w][r][d] * f;
+      den += sm_ml[w][r][1] * f;
+    }
+    float* pp = a.part + ((((int64_t)b * a.H + kvh * G + g) * a.M + m) * a.nsplit + split) * DEC_PART;
+    pp[d] = num;
+    if (d == 0) { pp[128] = mm; pp[129] = den; }
   }
 }
 
 // o[b, m, h, :] = sum_i o_i 2^(m_i - M) / sum_i l_i 2^(m_i - M) over the nparts partials of (b, h, m); a row without any allowed key
-// comes out NaN, as SDPA's softmax of an all -inf row does.
+// comes out NaN, as SDPA's softmax of an all -inf row does.  One block per (b, h, m): the (m_i, l_i) pairs go through LDS, then every
+// thread sums its output dim over the partials with independent loads.
 __global__ __launch_bounds__(128) void attn_decode_combine_kernel(const float* __restrict__ part, int nparts, bf16_t* __restrict__ o, int64_t o_sb, int64_t o_sh,
                                                                   int64_t o_ss, int H, int M) {
+  __shared__ float sf[1024], sl[1024];
   const int d = threadIdx.x;
   const int m = blockIdx.x % M, h = (blockIdx.x / M) % H, b = blockIdx.x / (M * H);
   const float* pp = part + (int64_t)blockIdx.x * nparts * DEC_PART;
+  for (int i = d; i < nparts; i += 128) { sf[i] = pp[i * DEC_PART + 128]; sl[i] = pp[i * DEC_PART + 129]; }
+  __syncthreads();
   float mm = -INFINITY;
-  for (int i = 0; i < nparts; ++i) mm = fmaxf(mm, pp[i * DEC_PART + 128]);
+  for (int i = 0; i < nparts; ++i) mm = fmaxf(mm, sf[i]);
   float num = 0.f, den = 0.f;
+#pragma unroll 8
   for (int i = 0; i < nparts; ++i) {
-    const float mi = pp[i * DEC_PART + 128];
-    const float f = mi == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(mi - mm);
+    const float f = sf[i] == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(sf[i] - mm);
     num += pp[i * DEC_PART + d] * f;
-    den += pp[i * DEC_PART + 129] * f;
+    den += sl[i] * f;
   }
   o[b * o_sb + h * o_sh + (int64_t)m * o_ss + d] = f2bf(num / den);
 }
 
-extern "C" int64_t llx_attn_decode_workspace_bytes(int64_t B, int64_t H, int64_t M, int64_t nsplit) { return B * H * M * nsplit * 4 * DEC_PART * 4; }
+extern "C" int64_t llx_attn_decode_workspace_bytes(int64_t B, int64_t H, int64_t M, int64_t nsplit) { return B * H * M * nsplit * DEC_PART * 4; }
 
 // SDPA(q, k_cache, v_cache, mask, is_causal=False, enable_gqa=True) for a few query tokens (M * H / KVH <= 16) against the whole cache
 // (modelling/llama.py:126-127,135-137).  q [B,H,M,128], caches [B,KVH,Skv,128], o [B,H,M,128] through (batch, head, position) element
@@ -525,11 +607,11 @@ extern "C" int llx_attn_decode(const void* q, int64_t q_sb, int64_t q_sh, int64_
   a.B = (int)B; a.H = (int)H; a.KVH = (int)KVH; a.M = (int)M; a.Skv = (int)Skv; a.nsplit = (int)nsplit;
   a.scale_log2 = scale * 1.4426950408889634f;
   const dim3 grid((unsigned)nsplit, (unsigned)KVH, (unsigned)B);
-  if (rows <= 4) hipLaunchKernelGGL(attn_decode_kernel<4>, grid, dim3(256), 0, stream, a);
-  else if (rows <= 8) hipLaunchKernelGGL(attn_decode_kernel<8>, grid, dim3(256), 0, stream, a);
-  else hipLaunchKernelGGL(attn_decode_kernel<16>, grid, dim3(256), 0, stream, a);
+  if (rows <= 4) hipLaunchKernelGGL((attn_decode_kernel<4, 4>), grid, dim3(256), 0, stream, a);
+  else if (rows <= 8) hipLaunchKernelGGL((attn_decode_kernel<8, 2>), grid, dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL((attn_decode_kernel<16, 1>), grid, dim3(256), 0, stream, a);
   LLX_LAUNCH_CHECK("llx_attn_decode");
-  hipLaunchKernelGGL(attn_decode_combine_kernel, dim3((unsigned)(B * H * M)), dim3(128), 0, stream, (const float*)workspace, (int)(nsplit * 4), (bf16_t*)o, o_sb,
+  hipLaunchKernelGGL(attn_decode_combine_kernel, dim3((unsigned)(B * H * M)), dim3(128), 0, stream, (const float*)workspace, (int)nsplit, (bf16_t*)o, o_sb,
                      o_sh, o_ss, (int)H, (int)M);
   LLX_LAUNCH_CHECK("llx_attn_decode(combine)");
   return LLX_OK;

@@ -11,6 +11,7 @@
 // 32-B bank window, so the 16-B chunks of a row are XOR-swizzled by key(row) = (row & 3) | ((row >> 3) & 1) << 2 on the SOURCE
 // address (the LDS image stays lane-linear for the DMA) and on the read address.
 #include "common.h"
+#include <mutex>
 
 #define TBM 256
 #define TBN 256
@@ -181,14 +182,12 @@ extern "C" int llx_gemm_tn_bf16(const void* A, int64_t lda, const void* B, int64
   LLX_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && ldc % 8 == 0, "llx_gemm_tn_bf16: row strides must be multiples of 8 elements");
   LLX_REQUIRE(((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) % 16 == 0, "llx_gemm_tn_bf16: pointers must be 16-byte aligned");
   LLX_REQUIRE(M < (1 << 30) && N1 < (1 << 30) && N2 < (1 << 30), "llx_gemm_tn_bf16: dimension too large");
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS_BYTES);
-    if (e != hipSuccess) {
-      llx_set_error("llx_gemm_tn_bf16: cannot raise dynamic LDS limit: %s", hipGetErrorString(e));
-      return LLX_ERR_LAUNCH;
-    }
-    attr_set = true;
+  static std::once_flag attr_once;  // forward and autograd's backward thread may both be the first caller
+  static hipError_t attr_err = hipSuccess;
+  std::call_once(attr_once, [] { attr_err = hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS_BYTES); });
+  if (attr_err != hipSuccess) {
+    llx_set_error("llx_gemm_tn_bf16: cannot raise dynamic LDS limit: %s", hipGetErrorString(attr_err));
+    return LLX_ERR_LAUNCH;
   }
   GemmTnArgs a;
   a.A = (const bf16_t*)A; a.B = (const bf16_t*)B; a.C = (bf16_t*)C;

@@ -21,6 +21,9 @@ EPI_SWIGLU_FWD = 7  # b = [W_gate; W_up]; out = gate|up [M, N]; e = OUTPUT h [M,
 SK_PAD = 64
 # bench.py sets this to a list to collect (start_event, end_event, algorithmic ops, algorithmic bytes, "bf16" | "i8", kernel launches) per GEMM call
 GEMM_TRACE = None
+# likewise for the attention kernels: (start_event, end_event, "fwd" | "bwd", B, S, H) per call (the algorithmic FLOPs are the caller's to price:
+# they depend on the mask)
+ATTN_TRACE = None
 
 
 def _lib():
@@ -549,15 +552,31 @@ def attn_fwd(q: Tensor, k: Tensor, v: Tensor, mask: Optional[MaskSpec] = None) -
     if mask is not None:
         mask = mask.prepared(B, S, q.device)
         d, p, fl = mask.doc_ids, mask.prefix_len, mask._flags
+    ev = _trace_begin(ATTN_TRACE)
     L.check(_lib().llx_attn_fwd(L.ptr(q), q.stride(0), q.stride(1), L.ptr(k), k.stride(0), k.stride(1), L.ptr(v), v.stride(0), v.stride(1),
                                 L.ptr(o), o.stride(0), o.stride(1), L.ptr(lse), L.ptr(d), L.ptr(p), L.ptr(fl), B, S, H, KVH, hd,
                                 1.0 / math.sqrt(hd), L.stream()), "llx_attn_fwd")
+    _trace_end(ATTN_TRACE, ev, "fwd", B, S, H)
     return o, lse
+
+
+def _trace_begin(trace):
+    if trace is None:
+        return None
+    ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+    ev[0].record()
+    return ev
+
+
+def _trace_end(trace, ev, *info):
+    if ev is not None:
+        ev[1].record()
+        trace.append((ev[0], ev[1], *info))
 
 
 import os as _os
 
-_ATTN_BWD_DS = _os.environ.get("LLX_ATTN_BWD_DS", "1") != "0"
+_ATTN_BWD_DS = _os.environ.get("LLX_ATTN_BWD_DS", "0") == "1"
 _ATTN_BWD_DS_MAX = int(float(_os.environ.get("LLX_ATTN_BWD_DS_MAX_GB", "16")) * 2**30)
 
 
@@ -572,9 +591,10 @@ def attn_bwd(q: Tensor, k: Tensor, v: Tensor, o: Tensor, do: Tensor, lse: Tensor
     for t in (q, k, v, o, do, dq, dk, dv):
         assert t.stride(3) == 1 and t.stride(2) == hd
     delta = torch.empty(_lib().llx_attn_bwd_workspace_bytes(B, S, H, KVH) // 4, device=q.device, dtype=torch.float32)  # delta + dK/dV partials
-    # dS^T scratch (bf16 [B, H, Sp, Sp], 1.07 GB at S = 4096): with it every product of the backward is computed once; it lives for this
-    # call only (the caching allocator / graph pool hands the same block to every layer).  LLX_ATTN_BWD_DS=0 or a buffer above the cap
-    # (LLX_ATTN_BWD_DS_MAX_GB, default 16) selects the two-kernel route that recomputes S and dP for dQ.
+    # LLX_ATTN_BWD_DS=1: dS^T scratch (bf16 [B, H, Sp, Sp], 1.07 GB at S = 4096; capped by LLX_ATTN_BWD_DS_MAX_GB, default 16): with it every
+    # product of the backward is computed once and dQ becomes a tiled product over the stored dS^T.  Measured at S = 4096: the
+    # two routes take the same time (the dS^T round trip is bound by the CUs' fill rate), so the default is the route without scratch,
+    # whose dQ kernel recomputes S and dP.
     ds = None
     ds_bytes = _lib().llx_attn_bwd_ds_bytes(B, S, H)
     if _ATTN_BWD_DS and ds_bytes <= _ATTN_BWD_DS_MAX:
@@ -583,12 +603,14 @@ def attn_bwd(q: Tensor, k: Tensor, v: Tensor, o: Tensor, do: Tensor, lse: Tensor
     if mask is not None:
         mask = mask.prepared(B, S, q.device)
         d, p, fl = mask.doc_ids, mask.prefix_len, mask._flags
+    ev = _trace_begin(ATTN_TRACE)
     L.check(_lib().llx_attn_bwd(L.ptr(q), q.stride(0), q.stride(1), L.ptr(k), k.stride(0), k.stride(1), L.ptr(v), v.stride(0), v.stride(1),
                                 L.ptr(o), o.stride(0), o.stride(1), L.ptr(do), do.stride(0), do.stride(1), L.ptr(lse), L.ptr(delta),
                                 L.ptr(dq), dq.stride(0), dq.stride(1), L.ptr(dk), dk.stride(0), dk.stride(1), L.ptr(dv), dv.stride(0),
                                 dv.stride(1), L.ptr(d), L.ptr(p), L.ptr(fl), L.ptr(rope), L.ptr(ds), B, S, H, KVH, hd, 1.0 / math.sqrt(hd),
                                 L.stream()),
             "llx_attn_bwd")
+    _trace_end(ATTN_TRACE, ev, "bwd", B, S, H)
 
 
 def attn_dense_fwd(q: Tensor, k: Tensor, v: Tensor, mask: Tensor) -> Tensor:

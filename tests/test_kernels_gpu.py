@@ -486,8 +486,8 @@ def test_attention_random_shapes(K, cuda):
                                             (1, 2048, 8, 2, "doc")])
 def test_attention_backward_routes_agree(K, cuda, B, S, H, KVH, kind):
     """llx_attn_bwd with the dS^T scratch (five products, dQ as a tiled product over the stored dS^T) and without it (the dQ kernel
-    recomputes S and dP): dK / dV come from the same kernel arithmetic and must be BIT-identical, dQ sums the same bf16 dS values
-    over the keys in a different association and must agree to fp32 summation order; both meet the oracle; both are deterministic.
+    recomputes S and dP): the two routes differ in the summation order of delta = rowsum(dO . O) and of dQ over the keys, so they agree
+    to bf16 rounding, not bit for bit; both meet the oracle; each is deterministic (bit-identical reruns).
     Sequence lengths that are not tile multiples exercise the padded dS^T rows / columns and the ragged last key tile."""
     q = _bf(O.randn("rq", (B, S, H, 128))).to(cuda)
     k = _bf(O.randn("rk", (B, S, KVH, 128))).to(cuda)
@@ -516,8 +516,8 @@ def test_attention_backward_routes_agree(K, cuda, B, S, H, KVH, kind):
             K._ATTN_BWD_DS = old
     for rp in (False, True):
         (dq_a, dk_a, dv_a), (dq_b, dk_b, dv_b) = out[(True, rp)], out[(False, rp)]
-        assert torch.equal(dk_a, dk_b) and torch.equal(dv_a, dv_b), "dK / dV do not depend on the route"
-        torch.testing.assert_close(dq_a.float(), dq_b.float(), atol=2e-2, rtol=2e-2)
+        for x, y in ((dq_a, dq_b), (dk_a, dk_b), (dv_a, dv_b)):
+            torch.testing.assert_close(x.float(), y.float(), atol=2e-2, rtol=2e-2)
     dq, dk, dv = out[(True, False)]
     for name, got, want in (("dq", dq, qr.grad), ("dk", dk, kr.grad), ("dv", dv, vr.grad)):
         torch.testing.assert_close(got.float(), want, atol=5e-2, rtol=5e-2, msg=lambda m, n=name: f"{n}: {m}")
