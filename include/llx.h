@@ -201,6 +201,10 @@ int llx_scatter_rows(const void* src, int64_t ld_src, const int32_t* inv, const 
                      int64_t T, int64_t D, llx_stream_t s);
 int llx_ce_fwd_bwd_rows(const void* logits, int64_t ld, void* dlogits, int64_t dld, const int64_t* labels, float* loss, void* workspace,
                         int64_t T, int64_t V, const int32_t* rows, llx_stream_t s);
+/* the same loss over a row set walked in chunks (one logits buffer per chunk; labels / workspace cover all T rows): phase bit 0 = first
+ * chunk (count the labelled rows of the whole set), bit 1 = last chunk (reduce into loss); values identical to one call over all rows */
+int llx_ce_fwd_bwd_part(const void* logits, int64_t ld, void* dlogits, int64_t dld, const int64_t* labels, float* loss, void* workspace, int64_t T,
+                        int64_t V, int64_t row0, int64_t nrows, const int32_t* rows, int phase, llx_stream_t s);
 
 /* ---- LoRA skinny contractions (modelling/lora.py:43 and its autograd): T = X.W^T -> [M,64] zero padded;
  *      G = s * U^T.Y with fp32 split partials (deterministic). --------------------------------------------------- */

@@ -19,10 +19,13 @@ __global__ void ce_count_kernel(const int64_t* __restrict__ labels, float* __res
 // logits / dlogits carry no __restrict__: the caller passes the same buffer for both (in-place gradient).
 __global__ __launch_bounds__(CE_THREADS) void ce_row_kernel(const bf16_t* logits, bf16_t* dlogits, int64_t ld,
                                                              int64_t dld, const int64_t* __restrict__ labels, float* __restrict__ row_loss,
-                                                             const float* __restrict__ inv_count, int V, const int32_t* __restrict__ rows_dyn) {
+                                                             const float* __restrict__ inv_count, int V, const int32_t* __restrict__ rows_dyn,
+                                                             int64_t row0) {
+  // (row0: index of this launch's first row in the whole row set - a launch may cover a chunk of it; logits / dlogits / labels /
+  //  row_loss are passed pre-offset, only the comparison with the global labelled-row count needs the absolute index)
   __shared__ float red[16];
   const int64_t t = blockIdx.x;
-  if (rows_dyn != nullptr && t >= ((rows_dyn[0] + 255) & ~255)) {  // compacted rows: nothing reads past the last row tile of the GEMMs
+  if (rows_dyn != nullptr && row0 + t >= ((rows_dyn[0] + 255) & ~255)) {  // compacted rows: nothing reads past the last row tile of the GEMMs
     if (threadIdx.x == 0) row_loss[t] = 0.f;
     return;
   }
@@ -99,7 +102,7 @@ static int ce_fwd_bwd_impl(const void* logits, int64_t ld, void* dlogits, int64_
   hipLaunchKernelGGL(ce_count_kernel, dim3(1), dim3(1024), 0, stream, labels, ws, T);
   LLX_LAUNCH_CHECK("llx_ce_fwd_bwd(count)");
   hipLaunchKernelGGL(ce_row_kernel, dim3((unsigned)T), dim3(CE_THREADS), 0, stream, (const bf16_t*)logits, (bf16_t*)dlogits, ld, dld, labels,
-                     ws + 2, ws, (int)V, rows_dyn);
+                     ws + 2, ws, (int)V, rows_dyn, (int64_t)0);
   LLX_LAUNCH_CHECK("llx_ce_fwd_bwd(rows)");
   hipLaunchKernelGGL(ce_reduce_kernel, dim3(1), dim3(1024), 0, stream, ws + 2, ws, loss, T);
   LLX_LAUNCH_CHECK("llx_ce_fwd_bwd(reduce)");
@@ -117,6 +120,31 @@ extern "C" int llx_ce_fwd_bwd_rows(const void* logits, int64_t ld, void* dlogits
                                    void* workspace, int64_t T, int64_t V, const int32_t* rows, hipStream_t stream) {
   LLX_REQUIRE(rows && (uintptr_t)rows % 4 == 0, "llx_ce_fwd_bwd_rows: rows must be a device int32 pointer");
   return ce_fwd_bwd_impl(logits, ld, dlogits, dld, labels, loss, workspace, T, V, rows, stream);
+}
+
+// The same loss over a row set too large for one logits buffer (the GEMM's 32-bit tile offsets stop at 4 GiB = 16.7 k rows of a
+// 128 k vocabulary): the caller walks the rows in chunks, one call per chunk with that chunk's logits; `labels` and `workspace` cover
+// ALL T rows.  phase bit 0 (first chunk): count the labelled rows of the whole set first; bit 1 (last chunk): reduce the per-row
+// losses of the whole set into `loss`.  Every row sees the global 1 / n_valid, so the values are those of one call over all rows.
+extern "C" int llx_ce_fwd_bwd_part(const void* logits, int64_t ld, void* dlogits, int64_t dld, const int64_t* labels, float* loss, void* workspace,
+                                   int64_t T, int64_t V, int64_t row0, int64_t nrows, const int32_t* rows, int phase, hipStream_t stream) {
+  LLX_REQUIRE(logits && labels && loss && workspace, "llx_ce_fwd_bwd_part: null pointer");
+  LLX_REQUIRE(V % 8 == 0 && ld % 8 == 0 && dld % 8 == 0, "llx_ce_fwd_bwd_part: V and row strides must be multiples of 8");
+  LLX_REQUIRE(T > 0 && V > 0 && V < (1 << 30) && row0 >= 0 && nrows > 0 && row0 + nrows <= T, "llx_ce_fwd_bwd_part: bad sizes");
+  LLX_REQUIRE(rows == nullptr || (uintptr_t)rows % 4 == 0, "llx_ce_fwd_bwd_part: rows must be a device int32 pointer");
+  float* ws = (float*)workspace;
+  if (phase & 1) {
+    hipLaunchKernelGGL(ce_count_kernel, dim3(1), dim3(1024), 0, stream, labels, ws, T);
+    LLX_LAUNCH_CHECK("llx_ce_fwd_bwd_part(count)");
+  }
+  hipLaunchKernelGGL(ce_row_kernel, dim3((unsigned)nrows), dim3(CE_THREADS), 0, stream, (const bf16_t*)logits, (bf16_t*)dlogits, ld, dld, labels + row0,
+                     ws + 2 + row0, ws, (int)V, rows, row0);
+  LLX_LAUNCH_CHECK("llx_ce_fwd_bwd_part(rows)");
+  if (phase & 2) {
+    hipLaunchKernelGGL(ce_reduce_kernel, dim3(1), dim3(1024), 0, stream, ws + 2, ws, loss, T);
+    LLX_LAUNCH_CHECK("llx_ce_fwd_bwd_part(reduce)");
+  }
+  return LLX_OK;
 }
 
 // ------------------------------------------------------------------------------------------ LM-head row compaction

@@ -71,6 +71,7 @@ SIGNATURES: dict[str, tuple] = {
     "llx_ce_workspace_bytes": (c_int64, [_L]),
     "llx_ce_fwd_bwd": (c_int, [_P, _L, _P, _L, _P, _P, _P, _L, _L, _P]),
     "llx_ce_fwd_bwd_rows": (c_int, [_P, _L, _P, _L, _P, _P, _P, _L, _L, _P, _P]),
+    "llx_ce_fwd_bwd_part": (c_int, [_P, _L, _P, _L, _P, _P, _P, _L, _L, _L, _L, _P, _I, _P]),
     "llx_head_compact_index": (c_int, [_P, _P, _P, _P, _P, _L, _P]),
     "llx_gather_rows": (c_int, [_P, _L, _P, _P, _P, _L, _L, _L, _P]),
     "llx_scatter_rows": (c_int, [_P, _L, _P, _P, _P, _L, _L, _L, _P]),

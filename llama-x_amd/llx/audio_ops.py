@@ -192,5 +192,13 @@ def audio_prefix_and_embed(model, audio: Tensor, tokens: Tensor):
         raise L.LlxError("audio_embed must be Conv1d(k3,s1,p1) -> GELU -> Conv1d(k3,s2,p1) -> GELU (modelling/audio.py:26-31)")
     mel = model.melspec(audio)  # (B, n_mels, frames); the last frame is dropped inside logmel_cmn_padded (audio.py:53)
     feat_pad = logmel_cmn_padded(mel)
-    x = AudioPrefixFn.apply(feat_pad, tokens, model.tok_embeddings.weight, conv1.weight, conv1.bias, conv2.weight, conv2.bias)
+    args = (feat_pad, tokens, model.tok_embeddings.weight, conv1.weight, conv1.bias, conv2.weight, conv2.bias)
+    if model.config.activation_checkpointing and torch.is_grad_enabled() and any(t.requires_grad for t in args[2:]):
+        # the reference checkpoints the conv stack (modelling/audio.py:56-57): z1 / z2 / h1 (3 x [B, 4096 .. 8192, D] at 81.92 s clips) are
+        # dropped after the forward and recomputed in backward - every tensor AudioPrefixFn keeps goes through save_for_backward
+        from torch.utils.checkpoint import checkpoint
+
+        x = checkpoint(AudioPrefixFn.apply, *args, use_reentrant=False)
+    else:
+        x = AudioPrefixFn.apply(*args)
     return x, x.shape[1] - tokens.shape[1]

@@ -539,6 +539,36 @@ class MaskSpec:
         return self
 
 
+def maskspec_from_dense(mask: Tensor, B: int, S: int) -> Optional[MaskSpec]:
+    """The MaskSpec whose rule  allow(q, k) = (k <= q or k < prefix_len[b]) and doc_ids[b, q] == doc_ids[b, k]  reproduces a dense
+    bool mask (the reference's small-shape route ``layer(x, rope, mask=...)``, modelling/llama.py:135-137,163-172) EXACTLY, or None.
+    Recognised: causal, prefix-LM (per-sample prefix), contiguous documents, and their combination.  Documents are read off the
+    sub-diagonal (q-1 and q share a document iff mask[q, q-1]), the prefix off the part above the diagonal (its last visible column);
+    the rule is then evaluated densely and compared bit for bit - any other mask (per-head masks, non-contiguous document ids,
+    arbitrary patterns) gives None.  One host synchronisation (the comparison) per distinct mask tensor; cached on the tensor."""
+    if mask.dtype is not torch.bool or mask.shape[-2:] != (S, S):
+        return None
+    m = mask
+    while m.dim() < 4:
+        m = m.unsqueeze(0)
+    if m.dim() != 4 or m.shape[1] != 1 or m.shape[0] not in (1, B):
+        return None
+    m = m[:, 0].expand(B, S, S)
+    idx = torch.arange(S, device=m.device)
+    upper = m & (idx[None, :, None] < idx[None, None, :])            # allowed pairs with k > q: only the prefix term can make them
+    seen = upper.any(dim=1)                                           # [B, S]: column k visible from some earlier row
+    prefix = torch.where(seen.any(dim=1), S - seen.flip(1).float().argmax(dim=1), torch.zeros(B, device=m.device, dtype=torch.int64)).to(torch.int64)
+    link = torch.diagonal(m, offset=-1, dim1=1, dim2=2)               # [B, S-1]: mask[q, q-1]
+    doc = torch.cat([torch.zeros(B, 1, dtype=torch.int64, device=m.device), (~link).to(torch.int64).cumsum(1)], dim=1)
+    rule = ((idx[None, None, :] <= idx[None, :, None]) | (idx[None, None, :] < prefix[:, None, None])) & (doc[:, :, None] == doc[:, None, :])
+    if not bool(torch.equal(rule, m)):
+        return None
+    has_doc, has_prefix = bool(doc.any()), bool(prefix.any())
+    if not has_doc and not has_prefix:
+        return MaskSpec()  # plain causal
+    return MaskSpec(doc.to(torch.int32) if has_doc else None, prefix.to(torch.int32) if has_prefix else None)
+
+
 def attn_fwd(q: Tensor, k: Tensor, v: Tensor, mask: Optional[MaskSpec] = None) -> tuple[Tensor, Tensor]:
     """q [B,S,H,128], k/v [B,S,KVH,128] (last two dims dense; batch/seq strides free) -> o [B,S,H,128], lse [B,H,S]."""
     _chk_bf16(q, k, v)
@@ -797,6 +827,19 @@ def ce_fwd_bwd(logits: Tensor, labels: Tensor, write_grad: bool, rows: Optional[
         L.check(_lib().llx_ce_fwd_bwd(L.ptr(lg), lg.stride(0), L.ptr(lg) if write_grad else None, lg.stride(0), L.ptr(labels), L.ptr(loss),
                                       L.ptr(ws), T, V, L.stream()), "llx_ce_fwd_bwd")
     return loss, (lg if write_grad else None)
+
+
+def ce_chunk(logits: Tensor, labels_all: Tensor, ws: Tensor, loss: Tensor, row0: int, write_grad: bool, rows: Optional[Tensor], first: bool,
+             last: bool) -> Optional[Tensor]:
+    """One chunk of ce_fwd_bwd over a row set walked in chunks: logits [n, V] are rows row0 .. row0+n of the set, labels_all / ws (float32,
+    T + 2) / loss cover the whole set.  Returns the chunk's d loss / d logits (in place) when write_grad."""
+    _chk_bf16(logits)
+    n, V = logits.shape
+    T = labels_all.numel()
+    L.check(_lib().llx_ce_fwd_bwd_part(L.ptr(logits), logits.stride(0), L.ptr(logits) if write_grad else None, logits.stride(0), L.ptr(labels_all),
+                                       L.ptr(loss), L.ptr(ws), T, V, row0, n, L.ptr(rows), (1 if first else 0) | (2 if last else 0), L.stream()),
+            "llx_ce_fwd_bwd_part")
+    return logits if write_grad else None
 
 
 # ------------------------------------------------------------------------------------------------- skinny (LoRA)

@@ -709,6 +709,8 @@ _HEAD_COMPACT = os.environ.get("LLX_HEAD_COMPACT", "1") != "0"  # LM head + loss
 # a round of 256 tiles lasts a quarter of the unsplit tile time, i.e. the time follows the labelled-row count in steps of 1/4 round
 # (3071 rows: 12 x 16 x 4 = 768 tiles = 3 full rounds; measured -0.5 ms against one long round, 2 ranges = 1.5 rounds gain nothing)
 _HEAD_SPLITK = max(1, int(os.environ.get("LLX_HEAD_SPLITK", "4")))
+_HEAD_CHUNK_FORCED = "LLX_HEAD_CHUNK_ROWS" in os.environ
+_HEAD_CHUNK_ROWS = max(256, int(os.environ.get("LLX_HEAD_CHUNK_ROWS", "8192")) // 256 * 256)  # rows per logits buffer of the chunked head
 _FUSE_NORM_QUANT = os.environ.get("LLX_FUSE_NORM_QUANT", "1") != "0"  # A/B knob: 0 = stand-alone activation quantiser after the RMSNorm
 _FUSE_ROPE = os.environ.get("LLX_FUSE_ROPE", "1") != "0"  # A/B knob: 0 = stand-alone rope kernel after the projection / before its dgrad
 
@@ -804,6 +806,35 @@ class HeadLossFn(Function):
         ctx.plain_head = not plan.int8 and plan.rank == 0 and plan.bias is None and plan.dora_m is None and not any(ctx.needs_input_grad[5:])
         ctx.compact = _HEAD_COMPACT and ctx.plain_head
         ctx.m_expect = None
+        T, V = x2.shape[0], plan.N
+        # T-chunked head: one [rows, V] logits buffer is limited by the GEMM's 32-bit tile offsets (4 GiB = 16.7 k rows of a 128 k
+        # vocabulary; the reference's packed [1, bs * S] batches get there at bs >= 5): beyond that the rows are walked in chunks - one
+        # logits buffer, one CE launch set and (in backward) one d-hidden product per chunk, the loss normalised by the global count of
+        # labelled rows.  Same per-row arithmetic: bit-identical to the unchunked path (LLX_HEAD_CHUNK_ROWS forces chunking for tests).
+        chunk = _HEAD_CHUNK_ROWS if (_HEAD_CHUNK_FORCED or T * V * 2 >= 2**32) else 0
+        if chunk and T > chunk:
+            if not ctx.plain_head:
+                raise LlxError(f"LM head over {T} rows x {V} vocabulary entries exceeds one logits buffer (4 GiB) and a trainable / adapted / "
+                               "quantised head is not chunked: freeze the plain head or lower the number of positions per step")
+            inv = cnt = None
+            rows_in, labels_in = xn, labels.reshape(-1).contiguous()
+            if ctx.compact:
+                idx, inv, labels_in, cnt = K.head_compact_index(labels)
+                rows_in = K.gather_rows(xn, idx, cnt)
+            w = plan.weight.detach()
+            ws = torch.empty(T + 2, device=x.device, dtype=torch.float32)
+            loss = torch.empty((), device=x.device, dtype=torch.float32)
+            parts = []
+            for r0 in range(0, T, chunk):
+                r1 = min(T, r0 + chunk)
+                cnt_c = torch.clamp(cnt - r0, min=0, max=r1 - r0).to(torch.int32) if cnt is not None else None  # labelled rows inside this chunk
+                lg = torch.empty(r1 - r0, V, device=x.device, dtype=BF16)
+                K.gemm_nt(rows_in[r0:r1], w, out=lg, m_valid=cnt_c)
+                parts.append((K.ce_chunk(lg, labels_in, ws, loss, r0, need_grad, cnt, r0 == 0, r1 == T), cnt_c))
+            ctx.chunk = chunk
+            _save(ctx, x, norm_w, x2, None, rstd, tuple(p[0] for p in parts), (inv, cnt, tuple(p[1] for p in parts)))
+            return loss
+        ctx.chunk = 0
         if ctx.compact:
             idx, inv, labels_c, cnt = K.head_compact_index(labels)
             xc = K.gather_rows(xn, idx, cnt)
@@ -830,6 +861,21 @@ class HeadLossFn(Function):
             # vocabulary - cut in K ranges computed side by side, so that fewer rows (12 x 16 tiles at 3071 labelled rows) still fill
             # the chip with full rounds of short tiles.  The compacted and the uncompacted path use the same split, so they stay
             # bit-identical to each other.
+            if ctx.chunk:  # chunked rows (see forward): d hidden chunk by chunk, then one scatter / scale over all rows
+                inv, cnt, cnts = t
+                dx = dnw = None
+                if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+                    wt = weight_t(plan.weight)
+                    T = x2.shape[0]
+                    split = wt.shape[1] % (64 * _HEAD_SPLITK) == 0
+                    dxc = torch.empty(T, wt.shape[0], device=x.device, dtype=BF16)
+                    for i, (dl, cnt_c) in enumerate(zip(dlogits, cnts)):
+                        r0 = i * ctx.chunk
+                        part = K.gemm_nt_splitk(dl, wt, _HEAD_SPLITK, m_valid=cnt_c) if split else K.gemm_nt(dl, wt, m_valid=cnt_c)
+                        dxc[r0 : r0 + dl.shape[0]].copy_(part)
+                    dxn = K.scatter_rows(dxc, inv, g32) if inv is not None else K.scale(dxc, dev_scalar=g32)
+                    dx, dnw = K.rmsnorm_bwd(dxn, x2, norm_w.detach(), rstd, ctx.needs_input_grad[1], dw_out=_grad_dst([norm_w]))
+                return (dx.view(x.shape) if dx is not None else None, dnw, None, None, None, *([None] * len(needs)))
             inv, cnt = t if ctx.compact else (None, None)
             dx = dnw = None
             if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:

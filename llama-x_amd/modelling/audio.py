@@ -3,8 +3,11 @@
 Front end: log-mel spectrogram (framed, windowed 512-point real DFT evaluated directly in fp32 on the VALU, |.|^2 and the
 slaney mel filterbank in the same kernel: csrc/audio.hip `mel_power_kernel`) -> log10 / clip / CMN (`logmel_cmn_kernel`) ->
 Conv1d(k3,s1)+GELU -> Conv1d(k3,s2)+GELU as implicit GEMMs over a time-major, zero-padded activation buffer
-(the im2col matrix of a k=3 convolution is a strided VIEW of that buffer) with bias+GELU fused in the GEMM epilogue.
-The second convolution writes straight into the [audio ; text] sequence buffer, so torch.cat (audio.py:63) never runs.
+(the im2col matrix of a k=3 convolution is a strided VIEW of that buffer): the bias rides in the GEMM epilogue, GELU is its own
+element-wise pass because the pre-activation z is what the backward needs (the fused bias+GELU epilogue exists for inference).
+The second GELU writes straight into the [audio ; text] sequence buffer, so torch.cat (audio.py:63) never runs.  With
+``config.activation_checkpointing`` the conv stack is checkpointed as the reference does (audio.py:56-57): its pre-activations are
+recomputed in backward instead of being kept.
 """
 from typing import NamedTuple
 
@@ -29,7 +32,7 @@ class LlamaAudio(Llama):
     def __init__(self, config: LlamaConfig, audio_config: AudioConfig = AudioConfig()):
         super().__init__(config)
         self.audio_config = audio_config
-        # inspired by Whisper encoder
+        # two-convolution front end; the Sequential's indices are the checkpoint keys audio_embed.{0,2}.{weight,bias}
         self.audio_embed = nn.Sequential(
             nn.Conv1d(audio_config.n_mels, config.embed_dim, 3, 1, 1),
             nn.GELU(),
@@ -59,19 +62,20 @@ class LlamaAudio(Llama):
 
     @staticmethod
     def from_hf(model_id: str, **kwargs):
-        audio_kwargs = {k: kwargs.pop(k) for k in list(kwargs) if k in AudioConfig._fields}
-        audio_config = AudioConfig(**audio_kwargs)
+        """A text checkpoint (hub id or local directory, as Llama.from_hf) plus a freshly initialised audio front end.
+        Keyword arguments named like AudioConfig fields configure the front end, the rest override LlamaConfig fields."""
+        audio_fields = {k: kwargs.pop(k) for k in tuple(kwargs) if k in AudioConfig._fields}  # (the reference pops while iterating: audio.py:81)
         config = _get_hf_config(model_id)._replace(**kwargs)
         with torch.device("meta"):
-            model = LlamaAudio(config, audio_config).eval()
-        incompat_keys = model.load_state_dict(_get_hf_state_dict(model_id), strict=False, assign=True)
-        if incompat_keys:
-            print(incompat_keys)
-        # audio_embed has no checkpoint weights: materialise from meta and initialise
-        model.audio_embed.to_empty(device="cpu")
-        model.audio_embed.to(dtype=model.tok_embeddings.weight.dtype)
-        for m in model.audio_embed.modules():
-            if isinstance(m, nn.Conv1d):
-                m.reset_parameters()
-        model.build_cache()
+            model = LlamaAudio(config, AudioConfig(**audio_fields)).eval()
+        report = model.load_state_dict(_get_hf_state_dict(model_id), strict=False, assign=True)
+        absent = [k for k in report.missing_keys if not k.startswith("audio_embed.")]
+        if absent or report.unexpected_keys:
+            print(report)  # the text checkpoint is expected to lack exactly the audio_embed.* entries
+        # the checkpoint has no audio weights: give the meta-device convolutions real storage in the model dtype and PyTorch's default init
+        dtype = model.tok_embeddings.weight.dtype
+        model.audio_embed.to_empty(device="cpu").to(dtype=dtype)
+        for conv in (model.audio_embed[0], model.audio_embed[2]):
+            conv.reset_parameters()
+        model.build_cache()  # after materialisation: buffers cannot be built under the meta device
         return model

@@ -164,6 +164,15 @@ class Attention(nn.Module):
         return ops.GroupPlan((self.wq, self.wk, self.wv)), ops.GroupPlan((self.wo,))
 
     def _run(self, x: Tensor, rope: Tensor, norm: nn.Module | None, residual: bool, mask, input_pos, block_mask, plans=None) -> Tensor:
+        if mask is not None and self.kv_cache is None and torch.is_grad_enabled() and (
+                x.requires_grad or any(p.requires_grad for p in self.parameters()) or (norm is not None and norm.weight.requires_grad)):
+            # training through the reference's dense-mask route (llama.py:135-137): a mask that the MaskSpec rule reproduces exactly
+            # (causal / prefix-LM / contiguous documents) runs on the fused kernels with their backward; anything else has no backward here
+            spec = ops._cached(mask, "maskspec", lambda: (K.maskspec_from_dense(mask, x.shape[0], x.shape[1]),))[0]
+            if spec is None:
+                raise LlxError("training with a dense mask= needs a mask of the form (k <= q or k < prefix[b]) and same-document "
+                               "(contiguous documents): pass block_mask=MaskSpec(doc_ids=..., prefix_len=...) for anything else")
+            mask, block_mask = None, (spec if (spec.doc_ids is not None or spec.prefix_len is not None) else None)
         if self.kv_cache is not None or mask is not None:
             return self._run_dense(x, rope, norm, residual, mask, input_pos)
         if self.training and self.attn_dropout > 0.0:

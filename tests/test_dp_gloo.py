@@ -128,6 +128,30 @@ def _worker(rank, world, port, q):
         (ref_model(data).sum() / world).backward()
         ok6 = ok6 and len(seen5) == 6 and all(torch.allclose(seen5[n], dict(ref_model.named_parameters())[n].grad, atol=1e-5) for n in seen5)
     ok3 = ok3 and ok6
+    # step 7: the N > 1 path of bench.py when the stage capture fails or --no-graph is given (StagedStep._eager, reached through
+    # `stepper._graphs = None`) on the reference's default trainable set in small: dense matrices (classic flat buckets whose views are
+    # installed as .grad) NEXT TO arena members (slices of the arena's gradient buffer) inside the same backward stage, so a stage
+    # owns one bucket per kind; the flat optimizer must see the rank-averaged gradients of both kinds, two steps in a row
+    m6 = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.Tanh(), torch.nn.Linear(16, 4), torch.nn.Linear(4, 1))
+    m6.load_state_dict(model.state_dict())
+    arena6 = TrainableArena(m6)  # biases -> arena, weights stay dense
+    stages6 = [lambda xx: m6[1](m6[0](xx)), lambda h: m6[3](m6[2](h)).sum()]
+    sparams6 = [list(m6[0].parameters()), list(m6[2].parameters()) + list(m6[3].parameters())]
+    opt6 = torch.optim.SGD(arena6.params(), lr=0.0)
+    seen6 = {}
+    opt6.register_step_pre_hook(lambda o, a, k: seen6.update(
+        {n: (arena6.grad_view(p) if arena6.contains(p) else p.grad).clone() for n, p in m6.named_parameters()}))
+    st6 = StagedStep(m6, stages6, sparams6, opt6, graph=True)  # graph requested ...
+    st6._graphs = None                                            # ... capture "failed": bench.py's fallback runs the stages eagerly
+    kinds = [(g, b["arena"]) for b, g in zip(st6.buckets.buckets, st6.buckets.group_of_bucket)]
+    ok7 = sorted(kinds) == [(0, False), (0, True), (1, False), (1, True)]
+    for _ in range(2):
+        loss6 = st6._eager((x,))
+        ref_model.zero_grad()
+        (ref_model(data).sum() / world).backward()
+        ok7 = ok7 and len(seen6) == 6 and all(torch.allclose(seen6[n], dict(ref_model.named_parameters())[n].grad, atol=1e-6) for n in seen6)
+        ok7 = ok7 and torch.allclose(loss6, model(x).sum().detach())
+    ok3 = ok3 and ok7
     q.put((rank, bool(ok), bool(ok2 and ok3), float(local_only.abs().sum())))
     dist.destroy_process_group()
 

@@ -199,6 +199,36 @@ def test_product_iterators_reproduce_reference_fixtures(tmp_path):
         assert isinstance(opt.param_groups[0]["lr"], torch.Tensor) and float(opt.param_groups[0]["lr"]) == np.float32(g[f"case_{i}"][n // 2])
 
 
+def test_dense_mask_is_recognised_as_a_maskspec_rule():
+    """llx.kernels.maskspec_from_dense: the reference's dense `mask=` route (modelling/llama.py:135-137) maps onto the MaskSpec rule when
+    the mask IS that rule (causal, prefix-LM per sample, contiguous documents, both together), bit for bit; anything else gives None."""
+    from llx import kernels as K
+
+    S = 96
+    idx = torch.arange(S)
+    sp = K.maskspec_from_dense(O.causal_mask(S), 1, S)
+    assert sp is not None and sp.doc_ids is None and sp.prefix_len is None
+    sp = K.maskspec_from_dense(O.prefix_lm_mask(S, [40, 7]), 2, S)
+    assert sp.doc_ids is None and sp.prefix_len.tolist() == [40, 7]
+    sp = K.maskspec_from_dense(O.prefix_lm_mask(S, [1])[0, 0], 1, S)  # P = 1 is the causal mask
+    assert sp is not None and sp.prefix_len is None
+    doc = torch.zeros(S, dtype=torch.int64)
+    doc[20:] += 1
+    doc[50:] += 1
+    sp = K.maskspec_from_dense(O.document_mask(doc), 1, S)
+    assert sp.prefix_len is None and torch.equal(sp.doc_ids[0].long(), doc)
+    both = ((idx[None, :] <= idx[:, None]) | (idx[None, :] < 30)) & (doc[:, None] == doc[None, :])
+    sp = K.maskspec_from_dense(both[None, None], 1, S)
+    assert sp.prefix_len.tolist() == [30] and torch.equal(sp.doc_ids[0].long(), doc)
+    rule = ((idx[None, :] <= idx[:, None]) | (idx[None, :] < int(sp.prefix_len[0]))) & (sp.doc_ids[0][:, None] == sp.doc_ids[0][None, :])
+    assert torch.equal(rule, both)
+    tail = doc.clone()
+    tail[80:] = 0  # the packer's first-buffer quirk: the tail shares id 0 with the first document - not a contiguous-document mask
+    assert K.maskspec_from_dense(O.document_mask(tail), 1, S) is None
+    assert K.maskspec_from_dense(torch.rand(S, S, generator=torch.Generator().manual_seed(0)) < 0.5, 1, S) is None
+    assert K.maskspec_from_dense(O.causal_mask(S)[None, None].expand(1, 4, S, S), 1, S) is None  # per-head masks are not a MaskSpec
+
+
 # ---------------------------------------------------------------------------------------------- product API surface
 def test_module_api_and_state_dict_names():
     from modelling import AudioConfig, DoRALinear, Llama, LlamaAudio, LlamaConfig, LoRALinear, apply_linear_adapter_

@@ -369,10 +369,26 @@ def test_kv_cache_prefill_and_decode(cuda):
         out = layer(hid.to(cuda), model.rope[:384], mask=dense.to(cuda))
     want = O.layer(hid.float(), pf, 0, CFG, O.rope_table(CFG)[:384], dense)
     _close(out.float().cpu(), want, 0.03, "layer with dense prefix-LM mask")
+    # ... and under autograd (the reference trains through this route too, modelling/llama.py:135-137,163-172): a dense mask that the
+    # MaskSpec rule reproduces exactly runs on the fused kernels with their backward; an arbitrary one has no backward and raises
     from llx._lib import LlxError
 
+    xg = hid.to(cuda).requires_grad_()
+    dy = O.randn("dense_dy", (1, 384, 512), 0.1).bfloat16()
+    out_g = layer(xg, model.rope[:384], mask=dense.to(cuda))
+    out_g.backward(dy.to(cuda))
+    xr = hid.float().requires_grad_()
+    pr = {k: (v.clone().requires_grad_() if k.startswith("layers.0.") and k.endswith("_norm.weight") else v) for k, v in pf.items()}
+    ref = O.layer(xr, pr, 0, CFG, O.rope_table(CFG)[:384], dense)
+    ref.backward(dy.float())
+    _close(out_g.float().cpu(), ref.detach(), 0.03, "dense prefix-LM mask under autograd: output")
+    _close(xg.grad.float().cpu(), xr.grad, 0.05, "dense prefix-LM mask under autograd: dx")
+    _close(layer.attention_norm.weight.grad.float().cpu(), pr["layers.0.attention_norm.weight"].grad, 0.06, "d attention_norm.weight")
+    g = torch.Generator().manual_seed(3)
+    scattered = torch.rand(384, 384, generator=g) < 0.5
+    scattered |= torch.eye(384, dtype=torch.bool)
     with pytest.raises(LlxError):
-        layer(hid.to(cuda).requires_grad_(), model.rope[:384], mask=dense.to(cuda))
+        layer(hid.to(cuda).requires_grad_(), model.rope[:384], mask=scattered.to(cuda))
 
 
 def _mask_for(kind, S):
@@ -621,6 +637,35 @@ def test_activation_checkpointing_bit_identical_and_saves_memory(cuda):
     assert m1 < 0.75 * m0, f"checkpointing must lower peak activation memory: {m1 / 2**20:.0f} MiB vs {m0 / 2**20:.0f} MiB"
 
 
+def test_audio_embed_is_checkpointed_with_the_layers(cuda):
+    """LlamaAudio with activation_checkpointing=True also checkpoints the conv stack (modelling/audio.py:56-57): z1 / z2 / h1 of
+    AudioPrefixFn are dropped after the forward and recomputed in backward - bit-identical loss and conv / embedding gradients,
+    lower peak memory (a 20 s clip: 2000 frames at D = 512)."""
+    cfg = CFG._replace(num_layers=1, max_seq_len=1280)
+    pb, _ = bf16_params(O.init_params(cfg, audio=True))
+    audio = O.uniform("ck_audio", (2, 320000), -0.1, 0.1)
+    tokens, labels = _data(2, 128)
+    res = {}
+    for ckpt in (False, True):
+        model = build_model(cfg._replace(activation_checkpointing=ckpt), pb, cuda, audio=True)
+        for n, q in model.named_parameters():
+            q.requires_grad_(n.startswith("audio_embed") or n.startswith("tok_embeddings"))
+        torch.cuda.synchronize()
+        torch.cuda.reset_peak_memory_stats()
+        base = torch.cuda.memory_allocated()
+        loss = model(audio.to(cuda), tokens.to(cuda), labels=labels.to(cuda))
+        after_fwd = torch.cuda.memory_allocated() - base
+        loss.backward()
+        torch.cuda.synchronize()
+        res[ckpt] = (loss.detach().clone(), {n: q.grad.clone() for n, q in model.named_parameters() if q.grad is not None}, after_fwd)
+        del model, loss
+    (l0, g0, m0), (l1, g1, m1) = res[False], res[True]
+    assert torch.equal(l0, l1) and g0.keys() == g1.keys() and any(n.startswith("audio_embed") for n in g0)
+    for n in g0:
+        assert torch.equal(g0[n], g1[n]), n
+    assert m1 < 0.8 * m0, f"the conv stack's saved activations must be gone after the forward: {m1 / 2**20:.1f} MiB vs {m0 / 2**20:.1f} MiB"
+
+
 # ------------------------------------------------------------------------------------------------- A18 DoRA inside the fused blocks
 def test_dora_model_loss_and_grads(cuda):
     """apply_linear_adapter_(model.layers, "dora") (the scripts' --adapter dora): every linear of the fused attention / MLP blocks
@@ -699,3 +744,83 @@ def test_head_compaction_matches_uncompacted_path(cuda, pattern, monkeypatch):
     loss = model(tokens.to(cuda), labels=labels.to(cuda))
     loss.backward()
     assert model.output.weight.grad is not None and abs(loss.item() - out[False][0]) <= 2e-6 * abs(out[False][0])
+
+
+# ------------------------------------------------------------------------------------------------- T-chunked LM head
+@pytest.mark.parametrize("compact", [True, False])
+def test_chunked_head_is_bit_identical_to_one_buffer(cuda, compact, monkeypatch):
+    """HeadLossFn walks the rows in chunks when [T, V] logits do not fit one buffer (llx/ops.py: 4 GiB of bf16 = 16.7 k rows of the
+    128 k vocabulary).  Forced here at T = 4096 with 1024-row chunks (one chunk ends inside the labelled rows, the last ones hold
+    none on the compacted path): same per-row arithmetic, global count of labelled rows -> loss and every gradient bit-identical."""
+    from llx import ops
+
+    p = O.init_params(CFG)
+    p.update(O.init_lora(CFG, 8))
+    pb, _ = bf16_params(p)
+    cfg = CFG._replace(max_seq_len=2048)
+    tokens, labels = _data(2, 2048)
+    labels[1, 1500:] = -100
+    out = {}
+    for chunked in (False, True):
+        monkeypatch.setattr(ops, "_HEAD_COMPACT", compact)
+        monkeypatch.setattr(ops, "_HEAD_CHUNK_FORCED", chunked)
+        monkeypatch.setattr(ops, "_HEAD_CHUNK_ROWS", 1024)
+        model = build_model(cfg, pb, cuda, lora_rank=8)
+        for n, prm in model.named_parameters():
+            prm.requires_grad_("lora_" in n or n.endswith("norm.weight"))
+        loss = model(tokens.to(cuda), labels=labels.to(cuda))
+        loss.backward()
+        out[chunked] = (loss.detach().clone(), {n: prm.grad.clone() for n, prm in model.named_parameters() if prm.requires_grad})
+    assert torch.equal(out[True][0], out[False][0]), (out[True][0], out[False][0])
+    for n in out[True][1]:
+        assert torch.equal(out[True][1][n], out[False][1][n]), n
+    # a trainable head beyond one buffer is refused loudly instead of overflowing the tile offsets
+    from llx._lib import LlxError
+
+    monkeypatch.setattr(ops, "_HEAD_CHUNK_FORCED", True)
+    model = build_model(cfg, pb, cuda, lora_rank=8)
+    with pytest.raises(LlxError):
+        model(tokens.to(cuda), labels=labels.to(cuda))
+
+
+def test_chunked_head_at_20480_rows_of_the_full_vocabulary(cuda):
+    """T = 20 480 positions x V = 128 256 (5.25 GB of logits: more than the 4 GiB one GEMM operand may span; the reference's packed
+    [1, bs * S] batch at bs = 5, S = 4096): the chunked head runs, and equals the one-buffer head evaluated on four 5120-row slices
+    recombined with their labelled-row counts (loss: weighted mean; d hidden: slice gradient x n_slice / n_total)."""
+    from modelling import Llama, LlamaConfig
+
+    T, D, V = 20480, 4096, 128_256
+    cfg = LlamaConfig(embed_dim=D, num_layers=1, head_dim=128, num_heads=32, num_kv_heads=8, intermediate_dim=256, max_seq_len=64, vocab_size=V)
+    with torch.device("meta"):
+        model = Llama(cfg)
+    model = model.to(torch.bfloat16).to_empty(device=cuda)
+    g = torch.Generator(device=cuda).manual_seed(1)
+    with torch.no_grad():
+        model.output.weight.normal_(0.0, 0.02, generator=g)
+        model.norm.weight.fill_(1.0)
+    for q in model.parameters():
+        q.requires_grad_(False)
+    x = (torch.randn(1, T, D, device=cuda, generator=g) * 0.5).bfloat16()
+    labels = torch.randint(0, V, (1, T), device=cuda, generator=g)
+    labels[0, :3000] = -100
+    labels[0, 11000:12500] = -100
+    xa = x.clone().requires_grad_()
+    loss = model._head(xa, labels)
+    loss.backward()
+    n_tot = int((labels != -100).sum())
+    acc, parts = 0.0, []
+    for r0 in range(0, T, 5120):
+        xs = x[:, r0 : r0 + 5120].clone().requires_grad_()
+        ls = labels[:, r0 : r0 + 5120]
+        li = model._head(xs, ls)
+        li.backward()
+        n_i = int((ls != -100).sum())
+        acc += float(li) * n_i / n_tot
+        parts.append(xs.grad.float() * (n_i / n_tot))
+    assert abs(float(loss) - acc) <= 2e-5 * abs(acc), (float(loss), acc)
+    want = torch.cat(parts, dim=1)
+    got = xa.grad.float()
+    assert torch.equal(got[0, :3000], torch.zeros_like(got[0, :3000])), "ignore_index rows have a zero gradient"
+    err = (got - want).abs().max().item()
+    assert err <= 0.02 * want.abs().max().item(), (err, want.abs().max().item())
+
