@@ -159,12 +159,16 @@ def _roofline(args, config: str, kind: str, st: dict, S: int) -> dict:
             "gemm_ms_per_step": round(st["ms"], 2)}
 
 
-def run_workload(args, config: str, device, world: int, rank: int, steps: int, warmup: int, seq: int | None = None) -> dict:
+def run_workload(args, config: str, device, world: int, rank: int, steps: int, warmup: int, seq: int | None = None, head_compact: bool | None = None) -> dict:
     """Build the model of one BASELINE configuration, capture its step, time `steps` steps after `warmup`, then trace one eager step with
     HIP events around every GEMM launch (bf16 and i8 kernels separately).  Returns the raw numbers; main() formats them."""
     from llx import kernels as K
+    from llx import ops as llx_ops
     from llx.dp import GradBuckets
 
+    head_compact_default = llx_ops._HEAD_COMPACT
+    if head_compact is not None:
+        llx_ops._HEAD_COMPACT = head_compact  # A/B of the labelled-rows-only LM head (llx/ops.py HeadLossFn); restored below
     S = seq or args.seq
     model, cfg = build_model(args.model, S, args.rank, device, config, args.trainable)
     trainable = [p for p in model.parameters() if p.requires_grad]
@@ -363,6 +367,7 @@ def run_workload(args, config: str, device, world: int, rank: int, steps: int, w
                                     "flops": sum(e[2] for e in sel), "alg_bytes": sum(e[3] for e in sel)}
     res = {"config": config, "elapsed": elapsed, "steps": steps, "warmup": warmup, "per_step": per_step, "loss": float(loss.detach()),
            "launch": launch_mode, "gemm": gemm_stats, "attn": attn_stats, "info": info, "S": S}
+    llx_ops._HEAD_COMPACT = head_compact_default
     # release the 16 GB of weights + cached images + graph pools before the next workload is built
     del step, eager_step, run_model, model, optim, buckets, trainable
     graph = opt_graph = static_loss = stepper = None  # noqa: F841
@@ -528,6 +533,12 @@ def main():
             except Exception as exc:  # noqa: BLE001 - an extra workload must not cost the headline line
                 extras[cfg] = {"error": f"{type(exc).__name__}: {exc}"}
                 print(f"[bench] extra workload {cfg} failed: {exc}", file=sys.stderr, flush=True)
+        try:  # the headline workload with the LM head over ALL rows (LLX_HEAD_COMPACT=0): the step time the labelled-row head is quoted against
+            r_all = run_workload(args, "text", device, world, rank, args.extra_steps, 2, head_compact=False)
+            extras["text_head_all_rows"] = {k: v for k, v in _summary(args, r_all, world).items() if k in ("value", "unit", "ms_per_step", "p50_step_ms", "loss", "steps")}
+            extras["text_head_all_rows"]["lm_head_rows"] = "all"
+        except Exception as exc:  # noqa: BLE001
+            extras["text_head_all_rows"] = {"error": f"{type(exc).__name__}: {exc}"}
         if args.model == "llama31_8b":
             try:
                 extras["decode"] = run_decode(args, device, 20, 5)

@@ -42,19 +42,26 @@ struct AttnFwdArgs {
 };
 
 // GENERAL = false: pure causal (no doc_ids / prefix_len / tile flags) - the mask is index arithmetic only.
-template <bool GENERAL, bool STAMP = false>
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnFwdArgs a) {
+// NW = waves per workgroup (32 query rows each).  A K/V tile pair is 32 KiB of LDS-DMA per workgroup and key tile, and a CU takes
+// LDS-DMA fills at ~25-40 GB/s whatever their source (measured on the dQ-from-dS kernel, attn_bwd.hip): two 4-wave workgroups per CU
+// ask for ~60 GB/s at this kernel's MFMA rate, ONE 8-wave workgroup (256 query rows sharing every tile) for half of that.
+template <bool GENERAL, bool STAMP = false, int NW = 8>
+__global__ __launch_bounds__(64 * NW, 2) void attn_fwd_kernel(const AttnFwdArgs a) {
+  constexpr int WQ = 32 * NW;   // query rows per workgroup
+  constexpr int NP = 16 / NW;   // 1-KiB staging pieces per wave, tile and operand
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nqb = (a.S + BQ - 1) / BQ, nkt = (a.S + BKV - 1) / BKV;
+  const int nqb = (a.S + BQ - 1) / BQ, nkt = (a.S + BKV - 1) / BKV;  // 128-row blocks (granularity of the tile flags), key tiles
+  const int nwb = (a.S + WQ - 1) / WQ;
   // grid = (heads, q-blocks, batch): the q-block index is the SLOW dispatch dimension, so that under a causal mask the
   // heaviest blocks of EVERY head are handed out first (longest-processing-time order: no heavy straggler at the end)
-  const int qb = nqb - 1 - blockIdx.y;
+  const int qb = nwb - 1 - blockIdx.y;
   const int h = blockIdx.x, b = blockIdx.z;
   const int kvh = h / (a.H / a.KVH);
   const int r = lane & 31, hh = lane >> 5;
-  const int qi = qb * BQ + wave * 32 + r;  // this lane's query row
+  const int qi = qb * WQ + wave * 32 + r;  // this lane's query row
+  const int q_lo = qb * WQ + wave * 32;    // first query row of this wave
   const int qrow = min(qi, a.S - 1);
 
   // ---- Q fragments (B operand of S^T = K.Q^T): Q[q=r][d = 16ks + 8hh + j]
@@ -65,15 +72,20 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnFwdArgs a) {
     for (int ks = 0; ks < 8; ++ks) qf[ks] = *reinterpret_cast<const bf16x8_t*>(qp + 16 * ks);
   }
 
-  // ---- tile schedule
-  const uint8_t* fl = GENERAL ? a.flags + ((int64_t)b * nqb + qb) * nkt : nullptr;
-  const int kt_end = GENERAL ? nkt : min(nkt, (qb * BQ + BQ + BKV - 1) / BKV);
-  auto tile_class = [&](int t) -> int {
+  // ---- tile schedule.  The workgroup stages every key tile some wave needs; a wave computes the tiles ITS 32 rows need and classes
+  // them itself: 0 nothing to attend to (skipped), 1 partly masked, 2 no masking.  GENERAL: from the tile flags of the wave's own
+  // 128-row block (the workgroup's schedule = tiles either of its 128-row blocks needs); causal: index arithmetic on the wave's rows.
+  const int my_qb = min((qb * WQ + wave * 32) / BQ, nqb - 1);
+  const uint8_t* fl = GENERAL ? a.flags + ((int64_t)b * nqb + my_qb) * nkt : nullptr;
+  const uint8_t* fl0 = GENERAL ? a.flags + ((int64_t)b * nqb + min(qb * WQ / BQ, nqb - 1)) * nkt : nullptr;
+  const uint8_t* fl1 = GENERAL ? a.flags + ((int64_t)b * nqb + min(qb * WQ / BQ + (NW > 4 ? 1 : 0), nqb - 1)) * nkt : nullptr;
+  const int kt_end = GENERAL ? nkt : min(nkt, (qb * WQ + WQ + BKV - 1) / BKV);
+  auto tile_class = [&](int t) -> int {  // of this wave
     if constexpr (GENERAL) return fl[t];
-    else return (t * BKV + BKV - 1 <= qb * BQ) ? 2 : 1;  // all keys <= first query row of the block => no masking
+    else return (t * BKV > q_lo + 31) ? 0 : ((t * BKV + BKV - 1 <= q_lo) ? 2 : 1);
   };
-  auto next_tile = [&](int t) {
-    while (t < kt_end && tile_class(t) == 0) ++t;
+  auto next_tile = [&](int t) {  // of the workgroup
+    if constexpr (GENERAL) while (t < kt_end && fl0[t] == 0 && fl1[t] == 0) ++t;
     return t;
   };
 
@@ -82,10 +94,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnFwdArgs a) {
   const bf16_t* kbase = a.k + (int64_t)b * a.k_sb + kvh * HD;
   const bf16_t* vbase = a.v + (int64_t)b * a.v_sb + kvh * HD;
   // loop-invariant per-lane byte offsets inside a tile; the wave-uniform tile base advances by 64 rows per tile
-  uint32_t koff[4], voff[4];
+  uint32_t koff[NP], voff[NP];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = i * 16 + wave * 4 + srow_in;
+  for (int i = 0; i < NP; ++i) {
+    const int row = (i * NW + wave) * 4 + srow_in;
     koff[i] = (uint32_t)(((int64_t)row * a.k_ss + (sslot ^ (row & 15)) * 8) * 2);          // K image: slot = chunk ^ (row & 15)
     voff[i] = (uint32_t)(((int64_t)row * a.v_ss + (sslot ^ ((row & 3) << 2)) * 8) * 2);    // V image: slot = chunk ^ ((row & 3) << 2)
   }
@@ -96,19 +108,19 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnFwdArgs a) {
       const char* kt = (const char*)(kbase + (int64_t)t * BKV * a.k_ss);
       const char* vt = (const char*)(vbase + (int64_t)t * BKV * a.v_ss);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        __builtin_amdgcn_global_load_lds((gbl_void*)(kt + koff[i]), (lds_void*)(sK + (i * 16 + wave * 4) * 256), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gbl_void*)(vt + voff[i]), (lds_void*)(sV + (i * 16 + wave * 4) * 256), 16, 0, 0);
+      for (int i = 0; i < NP; ++i) {
+        __builtin_amdgcn_global_load_lds((gbl_void*)(kt + koff[i]), (lds_void*)(sK + (i * NW + wave) * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_void*)(vt + voff[i]), (lds_void*)(sV + (i * NW + wave) * 1024), 16, 0, 0);
       }
     } else {  // ragged last tile: clamp rows past the end (they are masked out)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int row = i * 16 + wave * 4 + srow_in;
+      for (int i = 0; i < NP; ++i) {
+        const int row = (i * NW + wave) * 4 + srow_in;
         const int key = min(t * BKV + row, a.S - 1);
         const int kc = sslot ^ (row & 15);
         const int vc = sslot ^ ((row & 3) << 2);
-        __builtin_amdgcn_global_load_lds((gbl_void*)(kbase + (int64_t)key * a.k_ss + kc * 8), (lds_void*)(sK + (i * 16 + wave * 4) * 256), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gbl_void*)(vbase + (int64_t)key * a.v_ss + vc * 8), (lds_void*)(sV + (i * 16 + wave * 4) * 256), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_void*)(kbase + (int64_t)key * a.k_ss + kc * 8), (lds_void*)(sK + (i * NW + wave) * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_void*)(vbase + (int64_t)key * a.v_ss + vc * 8), (lds_void*)(sV + (i * NW + wave) * 1024), 16, 0, 0);
       }
     }
   };
@@ -156,6 +168,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnFwdArgs a) {
     if (tn < kt_end) stage(cur ^ 1, tn);
     const char* sK = smem + cur * ATT_STAGE_BYTES;
     const char* sV = sK + KV_TILE_BYTES;
+    const int cls = tile_class(t);
+    if (cls != 0) {  // wave-uniform: a tile none of this wave's rows attends to is only staged (for the other waves)
 
     // ---- S^T = K.Q^T : 2 key blocks x 8 k-steps
     f32x16_t st[2];
@@ -174,7 +188,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnFwdArgs a) {
 
     stamp();  // 1: after QK^T
     // ---- mask, online softmax in log2 units (row statistics are per lane; the partner half-wave holds the other keys)
-    const int cls = tile_class(t);
     float mx = -INFINITY;
     if (cls != 2) {
 #pragma unroll
@@ -260,6 +273,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnFwdArgs a) {
       pv(I0{}, I2{});
       pv(I1{}, I3{});
     }
+    }  // cls != 0
 
     stamp();  // 3: after PV
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -333,12 +347,16 @@ extern "C" int llx_attn_fwd(const void* q, int64_t q_sb, int64_t q_ss, const voi
   LLX_REQUIRE(((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) % 16 == 0 && (uintptr_t)o % 8 == 0, "llx_attn_fwd: unaligned pointer");
   LLX_REQUIRE(!(doc_ids || prefix_len) || flags, "llx_attn_fwd: tile flags required with doc_ids/prefix_len");
   LLX_REQUIRE(S < (1 << 24), "llx_attn_fwd: S too large");
+  static int nw = 0;  // LLX_ATTN_FWD_NW=4: the 128-row workgroup (two per CU) this kernel had before, kept for A/B measurements
   {
     static std::once_flag once;  // forward may be entered from several host threads (activation checkpointing recomputes it in backward)
     static hipError_t err = hipSuccess;
     std::call_once(once, [] {
-      err = hipFuncSetAttribute((const void*)attn_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS_BYTES);
-      if (err == hipSuccess) err = hipFuncSetAttribute((const void*)attn_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS_BYTES);
+      const char* e = getenv("LLX_ATTN_FWD_NW");
+      nw = (e && e[0] == '4') ? 4 : 8;
+      const void* fns[4] = {(const void*)attn_fwd_kernel<false, false, 4>, (const void*)attn_fwd_kernel<true, false, 4>,
+                            (const void*)attn_fwd_kernel<false, false, 8>, (const void*)attn_fwd_kernel<true, false, 8>};
+      for (int i = 0; i < 4 && err == hipSuccess; ++i) err = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS_BYTES);
     });
     if (err != hipSuccess) { llx_set_error("llx_attn_fwd: %s", hipGetErrorString(err)); return LLX_ERR_LAUNCH; }
   }
@@ -349,17 +367,14 @@ extern "C" int llx_attn_fwd(const void* q, int64_t q_sb, int64_t q_ss, const voi
   a.B = (int)B; a.S = (int)S; a.H = (int)H; a.KVH = (int)KVH;
   a.scale_log2 = scale * 1.4426950408889634f;
   a.stamps = nullptr;
-  static int lds_bytes = 0;
-  if (!lds_bytes) {  // LLX_ATTN_LDS_PAD=1: experiment knob - ask for 96 KiB so that only ONE workgroup fits a CU
-    const char* e = getenv("LLX_ATTN_LDS_PAD");
-    lds_bytes = (e && e[0] == '1') ? 96 * 1024 : ATT_LDS_BYTES;
-    if (lds_bytes != ATT_LDS_BYTES) {
-      hipFuncSetAttribute((const void*)attn_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-      hipFuncSetAttribute((const void*)attn_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-    }
+  const dim3 grid((unsigned)H, (unsigned)cdiv64(S, 32 * nw), (unsigned)B), block(64 * nw);
+  if (nw == 8) {
+    if (a.flags) hipLaunchKernelGGL((attn_fwd_kernel<true, false, 8>), grid, block, ATT_LDS_BYTES, stream, a);
+    else hipLaunchKernelGGL((attn_fwd_kernel<false, false, 8>), grid, block, ATT_LDS_BYTES, stream, a);
+  } else {
+    if (a.flags) hipLaunchKernelGGL((attn_fwd_kernel<true, false, 4>), grid, block, ATT_LDS_BYTES, stream, a);
+    else hipLaunchKernelGGL((attn_fwd_kernel<false, false, 4>), grid, block, ATT_LDS_BYTES, stream, a);
   }
-  if (a.flags) hipLaunchKernelGGL(attn_fwd_kernel<true>, dim3((unsigned)H, (unsigned)cdiv64(S, BQ), (unsigned)B), dim3(256), lds_bytes, stream, a);
-  else hipLaunchKernelGGL(attn_fwd_kernel<false>, dim3((unsigned)H, (unsigned)cdiv64(S, BQ), (unsigned)B), dim3(256), lds_bytes, stream, a);
   LLX_LAUNCH_CHECK("llx_attn_fwd");
   return LLX_OK;
 }
@@ -367,8 +382,8 @@ extern "C" int llx_attn_fwd(const void* q, int64_t q_sb, int64_t q_ss, const voi
 // Diagnostic: resident workgroups per CU the runtime grants the forward kernel (occupancy API; advisory).
 extern "C" int llx_debug_attn_fwd_occupancy(void) {
   int n = -1;
-  hipFuncSetAttribute((const void*)attn_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS_BYTES);
-  hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)attn_fwd_kernel<false>, 256, ATT_LDS_BYTES);
+  hipFuncSetAttribute((const void*)attn_fwd_kernel<false, false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS_BYTES);
+  hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)attn_fwd_kernel<false, false, 8>, 512, ATT_LDS_BYTES);
   if (e != hipSuccess) { llx_set_error("occupancy query: %s", hipGetErrorString(e)); return -1; }
   return n;
 }
@@ -381,8 +396,8 @@ extern "C" int llx_debug_attn_fwd_stamps(const void* q, const void* k, const voi
   a.q_ss = H * HD; a.q_sb = S * a.q_ss; a.k_ss = KVH * HD; a.k_sb = S * a.k_ss; a.v_ss = a.k_ss; a.v_sb = a.k_sb; a.o_ss = a.q_ss; a.o_sb = a.q_sb;
   a.doc_ids = nullptr; a.prefix_len = nullptr; a.flags = nullptr; a.B = 1; a.S = (int)S; a.H = (int)H; a.KVH = (int)KVH;
   a.scale_log2 = 0.08838834764f * 1.4426950408889634f; a.stamps = stamps;
-  hipFuncSetAttribute((const void*)attn_fwd_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS_BYTES);
-  hipLaunchKernelGGL((attn_fwd_kernel<false, true>), dim3((unsigned)H, (unsigned)cdiv64(S, BQ), 1), dim3(256), ATT_LDS_BYTES, stream, a);
+  hipFuncSetAttribute((const void*)attn_fwd_kernel<false, true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS_BYTES);
+  hipLaunchKernelGGL((attn_fwd_kernel<false, true, 8>), dim3((unsigned)H, (unsigned)cdiv64(S, 256), 1), dim3(512), ATT_LDS_BYTES, stream, a);
   LLX_LAUNCH_CHECK("llx_debug_attn_fwd_stamps");
   return LLX_OK;
 }
