@@ -207,7 +207,10 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_kernel(const AttnFwdArgs 
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int e = 0; e < 16; ++e) mx = fmaxf(mx, st[kb][e]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * a.scale_log2;  // scale > 0: max commutes with the scaling
+    {  // combine with the partner half-wave: v_permlane32_swap (VALU) instead of a shuffle through the LDS crossbar
+      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+      mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1])) * a.scale_log2;  // scale > 0: max commutes with the scaling
+    }
     // Deferred running maximum: the base of the exponentials only moves when some row's maximum grew by more than 2^8 (one
     // wave-uniform decision per tile).  Until then p = exp2(s - m_stale) <= 256 - bf16 keeps its relative precision there and
     // O / l are normalised by the same base at the end - and the 64-register rescale of O is skipped on almost every tile.
@@ -224,7 +227,10 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_kernel(const AttnFwdArgs 
         st[kb][e] = p;
         rs += p;
       }
-    rs += __shfl_xor(rs, 32, 64);
+    {
+      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(rs), __float_as_uint(rs), false, false);
+      rs = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+    }
     if (move_base) {  // rescale every row to its current maximum (rows that did not move get alpha = 1)
       const float alpha = __builtin_amdgcn_exp2f(m_run - m_safe);  // m_run = -inf -> 0
       l_run *= alpha;
