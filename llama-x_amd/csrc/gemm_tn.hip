@@ -35,19 +35,26 @@ struct GemmTnArgs {
 
 __device__ __forceinline__ int tn_key(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
 
-// 16x16x32 operand for output index c0 + (lane & 15), k = 8 * (lane >> 4) + j of the 32-row k-step at `tile` (k-major, 512-B rows,
-// chunk swizzle as above).
-__device__ __forceinline__ bf16x8_t tn_frag(const char* tile, int c0, int lane) {
+// 16x16x32 operand for output index c0 + (lane & 15), k = 8 * (lane >> 4) + j of a 32-row k-step (k-major image, 512-B rows, chunk
+// swizzle as above): two ds_read_b64_tr_b16, rows r0 = 8g + q and r0 + 4 (same swizzle key: the second is 2048 bytes further).
+// tn_lane_off = byte offset of the first inside the k-step.  The reads are issued as inline asm (common.h: lds_tr_read_rt): through
+// the builtin hipcc put `s_waitcnt vmcnt(0)` in front of the first transposed read of every K-tile, which drained the LDS-DMA
+// prefetch of the next tile issued a few lines above it - the double buffer ran synchronously.
+__device__ __forceinline__ uint32_t tn_lane_off(int c0, int lane) {
   const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
-  const int col = c0 + 4 * p;                    // first of the 4 columns this lane's 8 bytes cover
+  const int col = c0 + 4 * p;                         // first of the 4 columns this lane's 8 bytes cover
   const int chunk = col >> 3, half = (col & 4) << 1;  // 16-B chunk, byte offset of the 8-B half
-  const int r0 = 8 * g + q, r1 = r0 + 4;
-  const char* p0 = tile + r0 * 512 + ((chunk ^ (tn_key(r0) << 1)) << 4) + half;
-  const char* p1 = tile + r1 * 512 + ((chunk ^ (tn_key(r1) << 1)) << 4) + half;
-  const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4t*)p0);
-  const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4t*)p1);
-  const s16x8t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-  return __builtin_bit_cast(bf16x8_t, v);
+  const int r0 = 8 * g + q;
+  return (uint32_t)(r0 * 512 + ((chunk ^ (tn_key(r0) << 1)) << 4) + half);
+}
+template <int N>
+__device__ __forceinline__ void tn_wait12(s16x4_t (&x)[12][2]) {
+  asm volatile("s_waitcnt lgkmcnt(%24)"
+               : "+v"(x[0][0]), "+v"(x[0][1]), "+v"(x[1][0]), "+v"(x[1][1]), "+v"(x[2][0]), "+v"(x[2][1]), "+v"(x[3][0]), "+v"(x[3][1]),
+                 "+v"(x[4][0]), "+v"(x[4][1]), "+v"(x[5][0]), "+v"(x[5][1]), "+v"(x[6][0]), "+v"(x[6][1]), "+v"(x[7][0]), "+v"(x[7][1]),
+                 "+v"(x[8][0]), "+v"(x[8][1]), "+v"(x[9][0]), "+v"(x[9][1]), "+v"(x[10][0]), "+v"(x[10][1]), "+v"(x[11][0]), "+v"(x[11][1])
+               : "n"(N));
+  __builtin_amdgcn_sched_barrier(0);
 }
 
 __global__ __launch_bounds__(512, 2) void gemm_tn_kernel(const GemmTnArgs g) {
@@ -98,6 +105,14 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_kernel(const GemmTnArgs g) {
     }
   };
 
+  // lane constants of the fragment reads: 4 B fragments (columns wn*64 + ni*16) and 8 A fragments (wm*128 + mi*16)
+  const uint32_t sbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  uint32_t foff[12];
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni) foff[ni] = tn_lane_off(wn * 64 + ni * 16, lane) + T_TILE_BYTES;
+#pragma unroll
+  for (int mi = 0; mi < 8; ++mi) foff[4 + mi] = tn_lane_off(wm * 128 + mi * 16, lane);
+
   f32x4_t acc[8][4];
 #pragma unroll
   for (int i = 0; i < 8; ++i)
@@ -115,16 +130,40 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_kernel(const GemmTnArgs g) {
     }
     __builtin_amdgcn_s_barrier();  // ... and every other wave's pieces
     asm volatile("" ::: "memory");
-    const char* sA = smem + cur * T_STAGE_BYTES;
-    const char* sB = sA + T_TILE_BYTES;
+    const uint32_t stage_base = sbase + cur * T_STAGE_BYTES;
     const bool ragged = kt * TBK + TBK > g.M;
+    // step 0's 24 reads and the 16 A-fragment reads of step 1 go out up front (the latter fly under the 32 MFMAs of step 0); step
+    // 1's 8 B-fragment reads reuse step 0's B registers once its MFMAs are issued (one more full set would not fit 256 registers)
+    s16x4_t fr[2][12][2];
+#pragma unroll
+    for (int f = 0; f < 12; ++f) {
+      lds_tr_read_rt(fr[0][f][0], stage_base + foff[f], 0);
+      lds_tr_read_rt(fr[0][f][1], stage_base + foff[f], 2048);
+    }
+#pragma unroll
+    for (int f = 4; f < 12; ++f) {
+      lds_tr_read_rt(fr[1][f][0], stage_base + foff[f], 32 * 512);
+      lds_tr_read_rt(fr[1][f][1], stage_base + foff[f], 32 * 512 + 2048);
+    }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
+      if (ks == 0) {
+        tn_wait12<15>(fr[0]);  // 40 reads in flight, <= 15 left: the 24 of step 0 are done (lgkmcnt counts in order)
+      } else {
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+          lds_tr_read_rt(fr[0][f][0], stage_base + foff[f], 32 * 512);
+          lds_tr_read_rt(fr[0][f][1], stage_base + foff[f], 32 * 512 + 2048);
+        }
+#pragma unroll
+        for (int f = 0; f < 4; ++f) { fr[1][f][0] = fr[0][f][0]; fr[1][f][1] = fr[0][f][1]; }
+        tn_wait12<0>(fr[1]);
+      }
       bf16x8_t bfr[4], af[8];
 #pragma unroll
-      for (int ni = 0; ni < 4; ++ni) bfr[ni] = tn_frag(sB + ks * 32 * 512, wn * 64 + ni * 16, lane);
+      for (int ni = 0; ni < 4; ++ni) bfr[ni] = frag_of(fr[ks][ni][0], fr[ks][ni][1]);
 #pragma unroll
-      for (int mi = 0; mi < 8; ++mi) af[mi] = tn_frag(sA + ks * 32 * 512, wm * 128 + mi * 16, lane);
+      for (int mi = 0; mi < 8; ++mi) af[mi] = frag_of(fr[ks][4 + mi][0], fr[ks][4 + mi][1]);
       if (ragged) {  // last K-tile of a contraction length that is not a multiple of 64: zero the A fragments of rows past M
         const int k0 = kt * TBK + ks * 32 + 8 * (lane >> 4);
 #pragma unroll
@@ -141,6 +180,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_kernel(const GemmTnArgs g) {
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ni], af[mi], acc[mi][ni], 0, 0, 0);
       __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // every wave is done reading stage `cur`: the next iteration may refill it
