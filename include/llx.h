@@ -27,7 +27,7 @@ extern "C" {
 typedef void* llx_stream_t; /* hipStream_t */
 
 /* ---- library ------------------------------------------------------------------------------------------------ */
-int llx_version(void);                                   /* 102 = 0.1.2 */
+int llx_version(void);                                   /* 103 = 0.1.3 */
 const char* llx_last_error_string(void);                 /* thread-local, valid until the next failing call */
 int llx_device_info(int device, char* name, int len);    /* returns CU count, fills gcn arch name */
 
@@ -81,6 +81,10 @@ int llx_gemm_nt_bf16_rope(const void* A, int64_t lda, const void* B, int64_t ldb
  *      transposed copies.  N1, N2 multiples of 8; any M. ------------------------------------------------------------------------------- */
 int llx_gemm_tn_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M, int64_t N1, int64_t N2,
                      llx_stream_t s);
+/* ... over the first min(M, *m_valid) rows only (m_valid: device int32, nullable): the weight gradient of a trainable LM head over the
+ * compacted labelled rows - F.cross_entropy's ignore_index rows have zero gradient rows (modelling/llama.py:216-218). */
+int llx_gemm_tn_bf16_rows(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M, int64_t N1, int64_t N2,
+                          const int32_t* m_valid, llx_stream_t s);
 
 /* ---- torchao::int8_mm_dequant(A, B, A_scale, B_scale) - subclasses/int8_mm.py:121-149 (Triton kernel :50-118).
  *      A int8 [M,K]; B passed as its K-contiguous rows [N,K] (= the reference's int_data.T view, strides (1,K));

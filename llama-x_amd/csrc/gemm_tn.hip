@@ -31,6 +31,7 @@ struct GemmTnArgs {
   int64_t lda, ldb, ldc;
   int M, N1, N2;  // contraction length, output rows, output columns
   int grid_m, grid_n;
+  const int* m_valid;  // nullable, device: only the first min(M, *m_valid) rows of A and B enter the product (read by the kernel: no host sync)
 };
 
 __device__ __forceinline__ int tn_key(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
@@ -93,13 +94,14 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_kernel(const GemmTnArgs g) {
     aoff[i] = (uint32_t)ca * 2;
     boff[i] = (uint32_t)cb * 2;
   }
-  const int nk = (g.M + TBK - 1) / TBK;
+  const int M = g.m_valid ? min(g.M, max(*g.m_valid, 0)) : g.M;  // workgroup-uniform
+  const int nk = (M + TBK - 1) / TBK;
   auto stage = [&](int buf, int kt) {
     char* sA = smem + buf * T_STAGE_BYTES;
     char* sB = sA + T_TILE_BYTES;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int64_t m = min(kt * TBK + srow[i], g.M - 1);  // rows past the end are re-reads of the last row; their products are zeroed
+      const int64_t m = min(kt * TBK + srow[i], M - 1);  // rows past the end are re-reads of the last row; their products are zeroed
       __builtin_amdgcn_global_load_lds((gbl_void*)((const char*)g.A + m * g.lda * 2 + aoff[i]), (lds_void*)(sA + (i * 512 + wave * 64) * 16), 16, 0, 0);
       __builtin_amdgcn_global_load_lds((gbl_void*)((const char*)g.B + m * g.ldb * 2 + boff[i]), (lds_void*)(sB + (i * 512 + wave * 64) * 16), 16, 0, 0);
     }
@@ -119,7 +121,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_kernel(const GemmTnArgs g) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  stage(0, 0);
+  if (nk > 0) stage(0, 0);  // (no rows: the tile is written as zeros)
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
     if (kt + 1 < nk) {
@@ -131,7 +133,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_kernel(const GemmTnArgs g) {
     __builtin_amdgcn_s_barrier();  // ... and every other wave's pieces
     asm volatile("" ::: "memory");
     const uint32_t stage_base = sbase + cur * T_STAGE_BYTES;
-    const bool ragged = kt * TBK + TBK > g.M;
+    const bool ragged = kt * TBK + TBK > M;
     // step 0's 24 reads and the 16 A-fragment reads of step 1 go out up front (the latter fly under the 32 MFMAs of step 0); step
     // 1's 8 B-fragment reads reuse step 0's B registers once its MFMAs are issued (one more full set would not fit 256 registers)
     s16x4_t fr[2][12][2];
@@ -170,7 +172,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_kernel(const GemmTnArgs g) {
         for (int mi = 0; mi < 8; ++mi) {
           s16x8t v = __builtin_bit_cast(s16x8t, af[mi]);
 #pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] = (k0 + j < g.M) ? v[j] : (short)0;
+          for (int j = 0; j < 8; ++j) v[j] = (k0 + j < M) ? v[j] : (short)0;
           af[mi] = __builtin_bit_cast(bf16x8_t, v);
         }
       }
@@ -214,8 +216,16 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_kernel(const GemmTnArgs g) {
 
 // C[N1,N2] = A[M,N1]^T . B[M,N2], bf16 in / out, fp32 accumulate.  lda / ldb / ldc: row strides in elements (multiples of 8; A and B
 // may be row-strided views, e.g. the im2col view of a convolution input).  N1, N2 multiples of 8 and >= 8; any M >= 1.
+// m_valid (nullable, device int32): the contraction runs over the first min(M, *m_valid) rows only - the compacted labelled rows of the
+// LM head's weight gradient, whose count lives on the device (llx_head_compact_index).
+extern "C" int llx_gemm_tn_bf16_rows(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M, int64_t N1, int64_t N2,
+                                     const int32_t* m_valid, hipStream_t stream);
 extern "C" int llx_gemm_tn_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M, int64_t N1, int64_t N2,
                                 hipStream_t stream) {
+  return llx_gemm_tn_bf16_rows(A, lda, B, ldb, C, ldc, M, N1, N2, nullptr, stream);
+}
+extern "C" int llx_gemm_tn_bf16_rows(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M, int64_t N1, int64_t N2,
+                                     const int32_t* m_valid, hipStream_t stream) {
   LLX_REQUIRE(A && B && C, "llx_gemm_tn_bf16: null pointer");
   LLX_REQUIRE(M > 0 && N1 >= 8 && N2 >= 8 && N1 % 8 == 0 && N2 % 8 == 0, "llx_gemm_tn_bf16: need M > 0 and N1, N2 multiples of 8 (M=%lld N1=%lld N2=%lld)",
               (long long)M, (long long)N1, (long long)N2);
@@ -234,6 +244,7 @@ extern "C" int llx_gemm_tn_bf16(const void* A, int64_t lda, const void* B, int64
   a.lda = lda; a.ldb = ldb; a.ldc = ldc;
   a.M = (int)M; a.N1 = (int)N1; a.N2 = (int)N2;
   a.grid_m = (int)cdiv64(N1, TBM); a.grid_n = (int)cdiv64(N2, TBN);
+  a.m_valid = m_valid;
   hipLaunchKernelGGL(gemm_tn_kernel, dim3(a.grid_m * a.grid_n), dim3(512), TN_LDS_BYTES, stream, a);
   LLX_LAUNCH_CHECK("llx_gemm_tn_bf16");
   return LLX_OK;

@@ -88,6 +88,7 @@ SIGNATURES: dict[str, tuple] = {
     "llx_splitk_combine": (c_int, [_P, _I, _L, _L, _P, _P, _P, _L, _P]),
     "llx_gemm_nt_bf16_rows": (c_int, [_P, _L, _P, _L, _P, _L, _L, _L, _L, _P, _L, _P, _L, _L, _I, _P, _L, _P, _P]),
     "llx_gemm_tn_bf16": (c_int, [_P, _L, _P, _L, _P, _L, _L, _L, _L, _P]),
+    "llx_gemm_tn_bf16_rows": (c_int, [_P, _L, _P, _L, _P, _L, _L, _L, _L, _P, _P]),
     "llx_gemm_nt_bf16_rope": (c_int, [_P, _L, _P, _L, _P, _L, _L, _L, _L, _P, _L, _P, _L, _L, _P, _L, _L, _P]),
 }
 

@@ -308,10 +308,11 @@ def lora_groups_pack(groups: list) -> list:
     return out
 
 
-def gemm_tn(a: Tensor, b: Tensor) -> Tensor:
+def gemm_tn(a: Tensor, b: Tensor, m_valid: Optional[Tensor] = None, m_expect: Optional[float] = None) -> Tensor:
     """a[M,N1]^T @ b[M,N2] -> [N1,N2] (weight gradients of dense linears / convolutions): the TN MFMA kernel reads both operands as they
     lie (token-major rows, row-strided views allowed).  Shapes it does not take (a dimension below 8 or not a multiple of 8, unaligned
-    views) go through transposed, zero-padded copies and the NT kernel."""
+    views) go through transposed, zero-padded copies and the NT kernel.  m_valid (device int32 scalar): only the first min(M, m_valid)
+    rows enter the product (the compacted labelled rows of the LM head); m_expect is its value for the FLOP accounting of a traced step."""
     _chk_bf16(a, b)
     assert a.dim() == 2 and b.dim() == 2 and a.shape[0] == b.shape[0] and a.stride(1) == 1 and b.stride(1) == 1
     M, N1 = a.shape
@@ -319,16 +320,22 @@ def gemm_tn(a: Tensor, b: Tensor) -> Tensor:
     ok = (N1 % 8 == 0 and N2 % 8 == 0 and N1 >= 8 and N2 >= 8 and a.stride(0) % 8 == 0 and b.stride(0) % 8 == 0
           and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0)
     if not ok:
+        if m_valid is not None:
+            raise L.LlxError("gemm_tn: a device-side row count needs the TN kernel's shapes (dimensions multiples of 8, 16-byte aligned rows)")
         return gemm_nt(transpose(a, 64), transpose(b, 64))
     out = torch.empty(N1, N2, device=a.device, dtype=BF16)
     ev = None
     if GEMM_TRACE is not None:
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         ev[0].record()
-    L.check(_lib().llx_gemm_tn_bf16(L.ptr(a), a.stride(0), L.ptr(b), b.stride(0), L.ptr(out), out.stride(0), M, N1, N2, L.stream()), "llx_gemm_tn_bf16")
+    if m_valid is not None:
+        assert m_valid.dtype is torch.int32 and m_valid.is_cuda and m_valid.numel() == 1
+    L.check(_lib().llx_gemm_tn_bf16_rows(L.ptr(a), a.stride(0), L.ptr(b), b.stride(0), L.ptr(out), out.stride(0), M, N1, N2,
+                                         L.ptr(m_valid) if m_valid is not None else None, L.stream()), "llx_gemm_tn_bf16")
     if ev is not None:
         ev[1].record()
-        GEMM_TRACE.append((ev[0], ev[1], 2.0 * M * N1 * N2, 2.0 * (M * N1 + M * N2 + N1 * N2), "bf16_tn", 1))
+        Me = M if m_expect is None else m_expect
+        GEMM_TRACE.append((ev[0], ev[1], 2.0 * Me * N1 * N2, 2.0 * (Me * N1 + Me * N2 + N1 * N2), "bf16_tn", 1))
     return out
 
 

@@ -802,9 +802,13 @@ class HeadLossFn(Function):
         xn, rstd = K.rmsnorm_fwd(x2, norm_w.detach(), eps)
         need_grad = any(ctx.needs_input_grad)
         ctx.plan, ctx.eps = plan, eps
-        # a frozen plain head (no adapter, no bias, bf16): only d hidden is wanted from its backward
-        ctx.plain_head = not plan.int8 and plan.rank == 0 and plan.bias is None and plan.dora_m is None and not any(ctx.needs_input_grad[5:])
-        ctx.compact = _HEAD_COMPACT and ctx.plain_head
+        # a plain head (no adapter, no bias, bf16).  Frozen: only d hidden is wanted from its backward.  Trainable (the reference's default,
+        # train_metamathqa.py:177-180): its weight gradient dW = d logits^T . norm(x) runs over the compacted rows too - the TN kernel reads
+        # the row count from device memory.
+        plain = not plan.int8 and plan.rank == 0 and plan.bias is None and plan.dora_m is None
+        ctx.plain_head = plain and not any(ctx.needs_input_grad[5:])
+        ctx.plain_trainable = plain and not ctx.plain_head and _HEAD_COMPACT
+        ctx.compact = _HEAD_COMPACT and plain
         ctx.m_expect = None
         T, V = x2.shape[0], plan.N
         # T-chunked head: one [rows, V] logits buffer is limited by the GEMM's 32-bit tile offsets (4 GiB = 16.7 k rows of a 128 k
@@ -843,7 +847,7 @@ class HeadLossFn(Function):
             ctx.m_expect = float(cnt.item()) if K.GEMM_TRACE is not None else None  # accounting of the traced eager step only
             K.gemm_nt(xc, w, out=logits, m_valid=cnt, m_expect=ctx.m_expect)
             loss, dlogits = K.ce_fwd_bwd(logits, labels_c, write_grad=need_grad, rows=cnt)
-            _save(ctx, x, norm_w, x2, None, rstd, dlogits, (inv, cnt))
+            _save(ctx, x, norm_w, x2, xc if ctx.plain_trainable else None, rstd, dlogits, (inv, cnt))
             return loss
         logits, t = plan.forward(xn)
         loss, dlogits = K.ce_fwd_bwd(logits, labels, write_grad=need_grad)
@@ -856,7 +860,7 @@ class HeadLossFn(Function):
         x, norm_w, x2, xn, rstd, dlogits, t = _load(ctx)
         needs = ctx.needs_input_grad[5:]
         g32 = gout.detach().to(torch.float32).reshape(1)
-        if ctx.plain_head:
+        if ctx.plain_head or ctx.plain_trainable:
             # d hidden = d logits . W: [T, D] is ONE round of 256 tiles whatever the row count, with a contraction over the whole
             # vocabulary - cut in K ranges computed side by side, so that fewer rows (12 x 16 tiles at 3071 labelled rows) still fill
             # the chip with full rounds of short tiles.  The compacted and the uncompacted path use the same split, so they stay
@@ -887,7 +891,10 @@ class HeadLossFn(Function):
                 else:
                     dxn = K.scale(K.gemm_nt(dlogits, wt), dev_scalar=g32)
                 dx, dnw = K.rmsnorm_bwd(dxn, x2, norm_w.detach(), rstd, ctx.needs_input_grad[1], dw_out=_grad_dst([norm_w]))
-            return (dx.view(x.shape) if dx is not None else None, dnw, None, None, None, *([None] * len(needs)))
+            gw = None
+            if ctx.plain_trainable:  # dW over the labelled rows (xn holds their gathered, normed activations), scaled by the incoming gradient
+                gw = K.scale(K.gemm_tn(dlogits, xn, m_valid=cnt, m_expect=ctx.m_expect), dev_scalar=g32)
+            return (dx.view(x.shape) if dx is not None else None, dnw, None, None, None, *([gw] + [None] * (len(needs) - 1) if needs else []))
         dxn, grads = plan.backward(dlogits, xn, t, needs, need_dx=ctx.needs_input_grad[0] or ctx.needs_input_grad[1])
         grads = [None if g is None else K.scale(g, dev_scalar=g32) for g in grads]
         dx = dnw = None

@@ -839,6 +839,21 @@ def test_gemm_tn(K, cuda, M, N1, N2):
     assert torch.equal(c, K.gemm_tn(a, b))
 
 
+@pytest.mark.parametrize("rows", [0, 1, 63, 64, 200, 333, 1000])
+def test_gemm_tn_device_row_count(K, cuda, rows):
+    """llx_gemm_tn_bf16_rows: the contraction stops at min(M, *m_valid) rows read from device memory (the LM head's weight gradient over
+    the compacted labelled rows); rows past the count may hold anything, NaN included."""
+    M, N1, N2 = 333, 512, 264
+    a = _bf(O.randn("tnr_a", (M, N1))).to(cuda)
+    b = _bf(O.randn("tnr_b", (M, N2))).to(cuda)
+    n = min(rows, M)
+    ref = a[:n].float().T @ b[:n].float()
+    a[n:] = float("nan")
+    b[n:] = float("inf")
+    c = K.gemm_tn(a, b, m_valid=torch.tensor([rows], device=cuda, dtype=torch.int32))
+    torch.testing.assert_close(c.float(), ref, atol=2 ** -7 * max(ref.abs().max().item(), 1e-6), rtol=2 ** -7)
+
+
 def test_gemm_tn_strided_views_and_fallback(K, cuda):
     """Row-strided operands (the im2col VIEW of a k=3, stride-2 convolution input; a column slice of a fused gradient buffer) go
     straight into the TN kernel; shapes it does not take (a dimension that is not a multiple of 8) fall back to the transposed copies."""

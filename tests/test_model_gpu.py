@@ -738,12 +738,22 @@ def test_head_compaction_matches_uncompacted_path(cuda, pattern, monkeypatch):
     assert out[True][1].keys() == out[False][1].keys() and len(out[True][1]) > 10
     for n in out[True][1]:
         assert torch.equal(out[True][1][n], out[False][1][n]), n
-    # a trainable head needs every row of xn for its weight gradient: the compaction must step aside
-    monkeypatch.setattr(ops, "_HEAD_COMPACT", True)
-    model = build_model(CFG, pb, cuda, lora_rank=8)
-    loss = model(tokens.to(cuda), labels=labels.to(cuda))
-    loss.backward()
-    assert model.output.weight.grad is not None and abs(loss.item() - out[False][0]) <= 2e-6 * abs(out[False][0])
+    # a trainable head (the reference's default, train_metamathqa.py:177-180): its weight gradient runs over the compacted rows as well
+    # (llx_gemm_tn_bf16_rows reads the count on the device) - same terms as the all-rows product in another fp32 summation order
+    got = {}
+    for compact in (True, False):
+        monkeypatch.setattr(ops, "_HEAD_COMPACT", compact)
+        model = build_model(CFG, pb, cuda, lora_rank=8)
+        loss = model(tokens.to(cuda), labels=labels.to(cuda))
+        loss.backward()
+        got[compact] = (loss.item(), model.output.weight.grad.clone(), model.norm.weight.grad.clone(), model.tok_embeddings.weight.grad.clone())
+    assert abs(got[True][0] - out[False][0]) <= 2e-6 * abs(out[False][0])
+    gw, gw0 = got[True][1].float(), got[False][1].float()
+    torch.testing.assert_close(gw, gw0, atol=2 ** -7 * gw0.abs().max().item(), rtol=2 ** -6)
+    assert torch.nn.functional.cosine_similarity(gw.flatten(), gw0.flatten(), dim=0).item() > 0.99999
+    for i in (2, 3):  # d hidden: the compacted path cuts the vocabulary contraction in K ranges, the all-rows trainable path does not
+        g1, g0 = got[True][i].float(), got[False][i].float()
+        torch.testing.assert_close(g1, g0, atol=2 ** -6 * g0.abs().max().item(), rtol=2 ** -5)
 
 
 # ------------------------------------------------------------------------------------------------- T-chunked LM head
