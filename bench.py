@@ -143,10 +143,13 @@ def _traffic(args, config: str, kind: str, S: int):
     measurement of this one."""
     if args.model != "llama31_8b":
         return None
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_{config}_s{S}_{kind}_gemm_hbm_traffic.json")))  # newest round last
     try:
-        with open(os.path.join(ROOT, "profiles", f"r02_{config}_s{S}_{kind}_gemm_hbm_traffic.json")) as f:
+        with open(files[-1]) as f:
             return round(json.load(f)["hbm_bytes_per_launch"])
-    except (OSError, KeyError, ValueError):
+    except (IndexError, OSError, KeyError, ValueError):
         return None
 
 

@@ -1,17 +1,25 @@
 #!/bin/bash
 # Regenerates the judged artefacts under profiles/ on a GPU box (run through gpurun from the repo root; results land in gpurun_out/refresh,
-# copy them into profiles/ afterwards):  kernel tables of the three workloads, the PMC passes (separate, as MI355X_MICROARCH.md prescribes)
-# for the GEMM traffic files and the per-kernel counter summary.
+# copy them into profiles/ afterwards with the round prefix):  kernel tables of the workloads (text, int8, audio, text with the reference's
+# default trainable set, single-token decode), the PMC passes (separate, as MI355X_MICROARCH.md prescribes) for the GEMM traffic files and
+# the per-kernel counter summary.  Steps run with && semantics: a failed GPU step ends the script.
 set -e
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+export LLX_ROUND=${LLX_ROUND:-r03}
 O=gpurun_out/refresh
 rm -rf $O && mkdir -p $O
-for cfg in text int8 audio; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_$cfg -o $cfg -- python3 bench.py --config $cfg --no-extras --no-cpu-baseline --steps 10 > $O/bench_$cfg.json 2> $O/bench_$cfg.err
-  python tools/kstats.py $O/kt_$cfg > $O/kstats_$cfg.md
-  cp $O/kt_$cfg/*/${cfg}_kernel_stats.csv $O/kstats_$cfg.csv 2>/dev/null || cp $O/kt_$cfg/${cfg}_kernel_stats.csv $O/kstats_$cfg.csv
-  echo "[refresh] kernel table $cfg done" 
-done
+kt() {  # kt <tag> <bench args...>
+  local tag=$1; shift
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_$tag -o $tag -- python3 bench.py "$@" --no-extras --no-cpu-baseline --steps 10 > $O/bench_$tag.json 2> $O/bench_$tag.err
+  python tools/kstats.py $O/kt_$tag > $O/kstats_$tag.md
+  cp $O/kt_$tag/*/${tag}_kernel_stats.csv $O/kstats_$tag.csv 2>/dev/null || cp $O/kt_$tag/${tag}_kernel_stats.csv $O/kstats_$tag.csv
+  echo "[refresh] kernel table $tag done"
+}
+kt text --config text
+kt int8 --config int8
+kt audio --config audio
+kt text_reference_trainable --config text --trainable reference
+kt decode --config decode
 for cfg in text int8 audio; do
   for pmc in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --pmc $pmc --output-format csv -d $O/pmc_${cfg}_$pmc -o p -- python3 bench.py --config $cfg --steps 1 --warmup 1 --no-graph --no-extras --no-cpu-baseline > /dev/null 2> $O/pmc_${cfg}_$pmc.err
