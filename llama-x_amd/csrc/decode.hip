@@ -458,28 +458,36 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const DecodeArgs a) {
   const bf16_t* vb = a.vc + b * a.c_sb + kvh * a.c_sh + c * 8;
   const bool shared_mask = a.m_sh == 0;  // the reference's mask (tril rows gathered at input_pos) is the same for every head
   const uint8_t* mbase = a.mask + b * a.m_sb;
-  for (int k0 = k_lo + wave * (4 * DEC_KPG); k0 < k_hi; k0 += 16 * DEC_KPG) {
-    u32x4_t kv[DEC_KPG], vv[DEC_KPG];
-    uint32_t allow[DEC_KPG];  // bit r: query row r may attend to key j
+  // Two register sets: the K / V rows and mask bytes of step i+1 are in flight while step i is computed - a wave walks only 2-8
+  // steps, so with the loads issued step by step every step paid a full HBM round trip (the kernel ran at 1.5 TB/s).  The mask bytes
+  // are only LOADED in the load step, unconditionally and with clamped indices: turning them into bits needs their values and would
+  // make the step wait for its own loads.
+  auto load_step = [&](int k0, u32x4_t (&kv)[DEC_KPG], u32x4_t (&vv)[DEC_KPG], uint8_t (&mb)[DEC_KPG][ROWS]) {
 #pragma unroll
     for (int j = 0; j < DEC_KPG; ++j) {
       const int key = k0 + j * 4 + grp;
       const int kk = min(key, a.Skv - 1);
       kv[j] = *reinterpret_cast<const u32x4_t*>(kb + (int64_t)kk * a.c_ss);
       vv[j] = *reinterpret_cast<const u32x4_t*>(vb + (int64_t)kk * a.c_ss);
-      uint32_t w = 0;
-      if (shared_mask) {
 #pragma unroll
-        for (int m = 0; m < ROWS; ++m)
-          if (m < a.M && mbase[(int64_t)m * a.m_sq + kk] != 0) w |= 1u << m;  // expanded to the G heads below
-      } else {
-#pragma unroll
-        for (int r = 0; r < ROWS; ++r) {
-          const int g = r / a.M, m = r % a.M;
-          if (g < G && mbase[(kvh * G + g) * a.m_sh + (int64_t)m * a.m_sq + kk] != 0) w |= 1u << r;
-        }
+      for (int r = 0; r < ROWS; ++r) {
+        // shared mask: entry m = token m (expanded to the G heads below); per-head mask: entry r = (head g, token m)
+        const int g = min(r / a.M, G - 1), m = shared_mask ? min(r, a.M - 1) : r % a.M;
+        mb[j][r] = mbase[(shared_mask ? (int64_t)0 : (int64_t)(kvh * G + g) * a.m_sh) + (int64_t)m * a.m_sq + kk];
       }
-      allow[j] = key < k_hi ? w : 0u;
+    }
+  };
+  auto compute_step = [&](int k0, const u32x4_t (&kv)[DEC_KPG], const u32x4_t (&vv)[DEC_KPG], const uint8_t (&mb)[DEC_KPG][ROWS]) {
+    uint32_t allow[DEC_KPG];  // shared mask: bit m = token m; per-head mask: bit r = query row r
+#pragma unroll
+    for (int j = 0; j < DEC_KPG; ++j) {
+      uint32_t w = 0;
+#pragma unroll
+      for (int r = 0; r < ROWS; ++r) {
+        const bool valid = shared_mask ? r < a.M : r / a.M < G;
+        if (valid && mb[j][r] != 0) w |= 1u << r;
+      }
+      allow[j] = (k0 + j * 4 + grp) < k_hi ? w : 0u;
     }
     float s[DEC_KPG][ROWS];
 #pragma unroll
@@ -519,6 +527,22 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const DecodeArgs a) {
         for (int j = 0; j < DEC_KPG; ++j) { lo = __builtin_fmaf(p[j], bflo(vv[j][e]), lo); hi = __builtin_fmaf(p[j], bfhi(vv[j][e]), hi); }
         o[r][2 * e] = lo; o[r][2 * e + 1] = hi;
       }
+    }
+  };
+  {
+    const int kstep = 16 * DEC_KPG;
+    u32x4_t kvA[DEC_KPG], vvA[DEC_KPG], kvB[DEC_KPG], vvB[DEC_KPG];
+    uint8_t mbA[DEC_KPG][ROWS], mbB[DEC_KPG][ROWS];
+    int k0 = k_lo + wave * (4 * DEC_KPG);
+    if (k0 < k_hi) load_step(k0, kvA, vvA, mbA);
+    while (k0 < k_hi) {
+      if (k0 + kstep < k_hi) load_step(k0 + kstep, kvB, vvB, mbB);
+      compute_step(k0, kvA, vvA, mbA);
+      k0 += kstep;
+      if (k0 >= k_hi) break;
+      if (k0 + kstep < k_hi) load_step(k0 + kstep, kvA, vvA, mbA);
+      compute_step(k0, kvB, vvB, mbB);
+      k0 += kstep;
     }
   }
   // merge the four lane groups of the wave (lanes l, l^16, l^32, l^48 hold the same dims of different keys), then the four waves

@@ -750,6 +750,9 @@ def kv_scatter(k: Tensor, v: Tensor, k_cache: Tensor, v_cache: Tensor, input_pos
 _DECODE_WS: dict = {}
 
 
+_DECODE_WGS = int(_os.environ.get("LLX_DECODE_WGS", "512"))
+
+
 def attn_decode(q: Tensor, k_cache: Tensor, v_cache: Tensor, mask: Tensor, extent: Optional[Tensor] = None, out: Optional[Tensor] = None) -> Tensor:
     """SDPA over the cache for a few query tokens: q [B, H, M, 128] (any strides, last dim dense), caches [B, KVH, Skv, 128], bool mask
     broadcastable to [B, H, M, Skv] -> o [B, H, M, 128] stored as [B, M, H*128] (the layout wo reads).  M * H / KVH <= 16."""
@@ -765,7 +768,7 @@ def attn_decode(q: Tensor, k_cache: Tensor, v_cache: Tensor, mask: Tensor, exten
         m = m.contiguous()
     m_sb = m.stride(0) if m.shape[0] != 1 else 0
     m_sh = m.stride(1) if m.shape[1] != 1 else 0
-    nsplit = max(1, min(-(-Skv // 32), -(-256 // (B * KVH)), 64))
+    nsplit = max(1, min(-(-Skv // 32), -(-_DECODE_WGS // (B * KVH)), 128))  # workgroups = nsplit * B * KVH: two or more per CU keep more rows in flight
     nbytes = _lib().llx_attn_decode_workspace_bytes(B, H, M, nsplit)
     key = (q.device, torch.cuda.current_stream(q.device).cuda_stream)
     ws = _DECODE_WS.get(key)
