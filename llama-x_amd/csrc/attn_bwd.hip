@@ -280,21 +280,36 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnBwdArgs a
 
   if (qi < a.S) {
     bf16_t* op = a.dq + (int64_t)b * a.dq_sb + (int64_t)qi * a.dq_ss + h * HD;
+    // (16-byte stores through a half-wave exchange per pair of column groups, as in the forward kernel's epilogue)
+    const bool wide = ((((uintptr_t)a.dq) | (uintptr_t)(a.dq_ss * 2) | (uintptr_t)(a.dq_sb * 2)) & 15) == 0;  // uniform
 #pragma unroll
     for (int db = 0; db < 4; ++db)
 #pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        u32x2_t pk;
-        pk[0] = pack_bf2(dq[db][4 * g4 + 0] * a.scale, dq[db][4 * g4 + 1] * a.scale);
-        pk[1] = pack_bf2(dq[db][4 * g4 + 2] * a.scale, dq[db][4 * g4 + 3] * a.scale);
-        if (a.rope) {  // gradient of apply_rope on the bf16-rounded dq, exactly as the stand-alone rope kernel computes it
-          const f32x4_t t = *reinterpret_cast<const f32x4_t*>(a.rope + ((int64_t)qi * 64 + ((32 * db + 8 * g4 + 4 * hh) >> 1)) * 2);
-          const float c0 = t[0], s0 = t[1] * -1.f, c1 = t[2], s1 = t[3] * -1.f;
-          const float x0 = bflo(pk[0]), x1 = bfhi(pk[0]), y0 = bflo(pk[1]), y1 = bfhi(pk[1]);
-          pk[0] = pack_bf2(x0 * c0 - x1 * s0, x1 * c0 + x0 * s0);
-          pk[1] = pack_bf2(y0 * c1 - y1 * s1, y1 * c1 + y0 * s1);
+      for (int j2 = 0; j2 < 2; ++j2) {
+        u32x2_t pp[2];
+#pragma unroll
+        for (int gg = 0; gg < 2; ++gg) {
+          const int g4 = 2 * j2 + gg;
+          u32x2_t pk;
+          pk[0] = pack_bf2(dq[db][4 * g4 + 0] * a.scale, dq[db][4 * g4 + 1] * a.scale);
+          pk[1] = pack_bf2(dq[db][4 * g4 + 2] * a.scale, dq[db][4 * g4 + 3] * a.scale);
+          if (a.rope) {  // gradient of apply_rope on the bf16-rounded dq, exactly as the stand-alone rope kernel computes it
+            const f32x4_t t = *reinterpret_cast<const f32x4_t*>(a.rope + ((int64_t)qi * 64 + ((32 * db + 8 * g4 + 4 * hh) >> 1)) * 2);
+            const float c0 = t[0], s0 = t[1] * -1.f, c1 = t[2], s1 = t[3] * -1.f;
+            const float x0 = bflo(pk[0]), x1 = bfhi(pk[0]), y0 = bflo(pk[1]), y1 = bfhi(pk[1]);
+            pk[0] = pack_bf2(x0 * c0 - x1 * s0, x1 * c0 + x0 * s0);
+            pk[1] = pack_bf2(y0 * c1 - y1 * s1, y1 * c1 + y0 * s1);
+          }
+          pp[gg] = pk;
         }
-        *reinterpret_cast<u32x2_t*>(op + 32 * db + 8 * g4 + 4 * hh) = pk;
+        if (wide) {
+          const auto r0 = __builtin_amdgcn_permlane32_swap(pp[0][0], pp[1][0], false, false);
+          const auto r1 = __builtin_amdgcn_permlane32_swap(pp[0][1], pp[1][1], false, false);
+          *reinterpret_cast<u32x4_t*>(op + 32 * db + 16 * j2 + 8 * hh) = u32x4_t{r0[0], r1[0], r0[1], r1[1]};
+        } else {
+          *reinterpret_cast<u32x2_t*>(op + 32 * db + 16 * j2 + 4 * hh) = pp[0];
+          *reinterpret_cast<u32x2_t*>(op + 32 * db + 16 * j2 + 8 + 4 * hh) = pp[1];
+        }
       }
   }
 }
@@ -799,21 +814,36 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq2_kernel(const AttnBwdArgs 
 
   if (qi < a.S) {
     bf16_t* op = a.dq + (int64_t)b * a.dq_sb + (int64_t)qi * a.dq_ss + h * HD;
+    // (16-byte stores through a half-wave exchange per pair of column groups, as in the forward kernel's epilogue)
+    const bool wide = ((((uintptr_t)a.dq) | (uintptr_t)(a.dq_ss * 2) | (uintptr_t)(a.dq_sb * 2)) & 15) == 0;  // uniform
 #pragma unroll
     for (int db = 0; db < 4; ++db)
 #pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        u32x2_t pk;
-        pk[0] = pack_bf2(dq[db][4 * g4 + 0] * a.scale, dq[db][4 * g4 + 1] * a.scale);
-        pk[1] = pack_bf2(dq[db][4 * g4 + 2] * a.scale, dq[db][4 * g4 + 3] * a.scale);
-        if (a.rope) {  // gradient of apply_rope on the bf16-rounded dq, exactly as the stand-alone rope kernel computes it
-          const f32x4_t t = *reinterpret_cast<const f32x4_t*>(a.rope + ((int64_t)qi * 64 + ((32 * db + 8 * g4 + 4 * hh) >> 1)) * 2);
-          const float c0 = t[0], s0 = t[1] * -1.f, c1 = t[2], s1 = t[3] * -1.f;
-          const float x0 = bflo(pk[0]), x1 = bfhi(pk[0]), y0 = bflo(pk[1]), y1 = bfhi(pk[1]);
-          pk[0] = pack_bf2(x0 * c0 - x1 * s0, x1 * c0 + x0 * s0);
-          pk[1] = pack_bf2(y0 * c1 - y1 * s1, y1 * c1 + y0 * s1);
+      for (int j2 = 0; j2 < 2; ++j2) {
+        u32x2_t pp[2];
+#pragma unroll
+        for (int gg = 0; gg < 2; ++gg) {
+          const int g4 = 2 * j2 + gg;
+          u32x2_t pk;
+          pk[0] = pack_bf2(dq[db][4 * g4 + 0] * a.scale, dq[db][4 * g4 + 1] * a.scale);
+          pk[1] = pack_bf2(dq[db][4 * g4 + 2] * a.scale, dq[db][4 * g4 + 3] * a.scale);
+          if (a.rope) {  // gradient of apply_rope on the bf16-rounded dq, exactly as the stand-alone rope kernel computes it
+            const f32x4_t t = *reinterpret_cast<const f32x4_t*>(a.rope + ((int64_t)qi * 64 + ((32 * db + 8 * g4 + 4 * hh) >> 1)) * 2);
+            const float c0 = t[0], s0 = t[1] * -1.f, c1 = t[2], s1 = t[3] * -1.f;
+            const float x0 = bflo(pk[0]), x1 = bfhi(pk[0]), y0 = bflo(pk[1]), y1 = bfhi(pk[1]);
+            pk[0] = pack_bf2(x0 * c0 - x1 * s0, x1 * c0 + x0 * s0);
+            pk[1] = pack_bf2(y0 * c1 - y1 * s1, y1 * c1 + y0 * s1);
+          }
+          pp[gg] = pk;
         }
-        *reinterpret_cast<u32x2_t*>(op + 32 * db + 8 * g4 + 4 * hh) = pk;
+        if (wide) {
+          const auto r0 = __builtin_amdgcn_permlane32_swap(pp[0][0], pp[1][0], false, false);
+          const auto r1 = __builtin_amdgcn_permlane32_swap(pp[0][1], pp[1][1], false, false);
+          *reinterpret_cast<u32x4_t*>(op + 32 * db + 16 * j2 + 8 * hh) = u32x4_t{r0[0], r1[0], r0[1], r1[1]};
+        } else {
+          *reinterpret_cast<u32x2_t*>(op + 32 * db + 16 * j2 + 4 * hh) = pp[0];
+          *reinterpret_cast<u32x2_t*>(op + 32 * db + 16 * j2 + 8 + 4 * hh) = pp[1];
+        }
       }
   }
 }

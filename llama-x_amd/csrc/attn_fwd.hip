@@ -293,14 +293,27 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_kernel(const AttnFwdArgs 
   if (qi < a.S) {
     const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
     bf16_t* op = a.o + (int64_t)b * a.o_sb + (int64_t)qi * a.o_ss + h * HD;
+    // A lane holds columns 8k+4hh..+3 of its row for 16 column groups k: stored as they lie that is 16 8-byte stores per lane, and the
+    // tail of a block is bound by the number of store instructions.  A half-wave exchange per pair of groups (v_permlane32_swap: the
+    // upper half's group-k words against the lower half's group-(k+1) words) leaves 16 contiguous bytes per lane - 8 stores.
+    const bool wide = ((((uintptr_t)a.o) | (uintptr_t)(a.o_ss * 2) | (uintptr_t)(a.o_sb * 2)) & 15) == 0;  // uniform
 #pragma unroll
     for (int db = 0; db < 4; ++db)
 #pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        u32x2_t pk;
-        pk[0] = pack_bf2(o[db][4 * g4 + 0] * inv, o[db][4 * g4 + 1] * inv);
-        pk[1] = pack_bf2(o[db][4 * g4 + 2] * inv, o[db][4 * g4 + 3] * inv);
-        *reinterpret_cast<u32x2_t*>(op + 32 * db + 8 * g4 + 4 * hh) = pk;
+      for (int j2 = 0; j2 < 2; ++j2) {
+        u32x2_t pa, pb2;
+        pa[0] = pack_bf2(o[db][8 * j2 + 0] * inv, o[db][8 * j2 + 1] * inv);
+        pa[1] = pack_bf2(o[db][8 * j2 + 2] * inv, o[db][8 * j2 + 3] * inv);
+        pb2[0] = pack_bf2(o[db][8 * j2 + 4] * inv, o[db][8 * j2 + 5] * inv);
+        pb2[1] = pack_bf2(o[db][8 * j2 + 6] * inv, o[db][8 * j2 + 7] * inv);
+        if (wide) {
+          const auto r0 = __builtin_amdgcn_permlane32_swap(pa[0], pb2[0], false, false);
+          const auto r1 = __builtin_amdgcn_permlane32_swap(pa[1], pb2[1], false, false);
+          *reinterpret_cast<u32x4_t*>(op + 32 * db + 16 * j2 + 8 * hh) = u32x4_t{r0[0], r1[0], r0[1], r1[1]};
+        } else {
+          *reinterpret_cast<u32x2_t*>(op + 32 * db + 16 * j2 + 4 * hh) = pa;
+          *reinterpret_cast<u32x2_t*>(op + 32 * db + 16 * j2 + 8 + 4 * hh) = pb2;
+        }
       }
     if (hh == 0 && a.lse) a.lse[((int64_t)b * a.H + h) * a.S + qi] = (l_run > 0.f) ? m_run + log2f(l_run) : -INFINITY;
   }
