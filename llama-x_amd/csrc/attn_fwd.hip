@@ -218,6 +218,21 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_kernel(const AttnFwdArgs 
     const bool move_base = __builtin_amdgcn_ballot_w64(m_cand > m_run + 8.f) != 0;
     const float m_new = move_base ? m_cand : m_run;
     const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
+    // (the V^T reads of the first two k-steps go out BEFORE the exponentials: their VALU time covers the LDS latency)
+    const uint32_t vb = sbase + cur * ATT_STAGE_BYTES + KV_TILE_BYTES;
+    s16x4_t Vl[2][4], Vh[2][4];
+    auto reads = [&](auto set_tag, auto step_tag) {
+      constexpr int st_ = decltype(set_tag)::value, off = decltype(step_tag)::value * 4096;  // step = (kb, s): 16 keys = 4096 bytes
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {
+        lds_tr_read<off>(Vl[st_][db], vb + aV[db]);
+        lds_tr_read<off + 2048>(Vh[st_][db], vb + aV[db]);  // the hi block: 8 rows further
+      }
+    };
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+    reads(I0{}, I0{});
+    reads(I1{}, I1{});
     float rs = 0.f;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
@@ -247,16 +262,6 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_kernel(const AttnFwdArgs 
     // V^T fragments by transposed reads issued as inline asm (common.h: lds_tr_read - the builtin form would drain the K/V prefetch
     // of the next tile right here): the 8 reads of step i+1 are in flight while the 4 MFMAs of step i run.
     {
-      const uint32_t vb = sbase + cur * ATT_STAGE_BYTES + KV_TILE_BYTES;
-      s16x4_t Vl[2][4], Vh[2][4];
-      auto reads = [&](auto set_tag, auto step_tag) {
-        constexpr int st_ = decltype(set_tag)::value, off = decltype(step_tag)::value * 4096;  // step = (kb, s): 16 keys = 4096 bytes
-#pragma unroll
-        for (int db = 0; db < 4; ++db) {
-          lds_tr_read<off>(Vl[st_][db], vb + aV[db]);
-          lds_tr_read<off + 2048>(Vh[st_][db], vb + aV[db]);  // the hi block: 8 rows further
-        }
-      };
       auto pv = [&](auto set_tag, auto step_tag) {
         constexpr int st_ = decltype(set_tag)::value, step = decltype(step_tag)::value;
         bf16x8_t pb;
@@ -268,10 +273,6 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_kernel(const AttnFwdArgs 
         for (int db = 0; db < 4; ++db) o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_of(Vl[st_][db], Vh[st_][db]), pb, o[db], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       };
-      using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
-      using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
-      reads(I0{}, I0{});
-      reads(I1{}, I1{});
       pv(I0{}, I0{});
       reads(I0{}, I2{});
       pv(I1{}, I1{});
