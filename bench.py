@@ -461,7 +461,7 @@ def _summary(args, r: dict, world: int) -> dict:
         tot_ms = at["fwd"]["ms"] + at["bwd"]["ms"]
         ach = (fl["fwd"] + fl["bwd"]) / (tot_ms * 1e-3) / 1e12
         d["roofline_attn"] = {"bound": "mfma", "achieved": round(ach, 1), "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / BF16_DENSE_PEAK_TFLOPS, 4),
-                              "traffic": None, "kernel": "attn_fwd_kernel + llx_attn_bwd (delta, dK/dV + dS^T store, reduce, dQ) - causal, algorithmic FLOPs",
+                              "traffic": None, "kernel": "attn_fwd_kernel + llx_attn_bwd (dQ [recomputes S, dP; publishes delta], dK/dV, reduce) - causal, algorithmic FLOPs (2 + 5 products; 7 executed in the backward)",
                               "fwd_us_per_layer": round(at["fwd"]["ms"] * 1e3 / at["fwd"]["calls"], 1), "bwd_us_per_layer": round(at["bwd"]["ms"] * 1e3 / at["bwd"]["calls"], 1),
                               "fwd_tflops": round(fl["fwd"] / (at["fwd"]["ms"] * 1e-3) / 1e12, 1), "bwd_tflops": round(fl["bwd"] / (at["bwd"]["ms"] * 1e-3) / 1e12, 1),
                               "attn_ms_per_step": round(tot_ms, 2)}

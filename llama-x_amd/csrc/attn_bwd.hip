@@ -80,7 +80,6 @@ struct AttnBwdArgs {
   const float* rope;  // nullable: fp32 table [>= S, 64, 2]; dq and dk leave the kernels already rotated by -theta (apply_rope's transpose)
   unsigned long long* stamps;  // diagnostic (normally null): s_memtime stamps of workgroup 0, wave 0 of the dK/dV kernel
   bf16_t* dq; bf16_t* dk; bf16_t* dv;
-  int probe;           // timing probes of the dQ-from-dS kernel (LLX_DQ2_PROBE; results are wrong): 1 = every dS^T tile read from tile 0, 2 = no MFMA / LDS reads
   bf16_t* ds; int Sp;  // route (a): dS^T per (b, h) as [Sp/64 key tiles][Sp/128 query blocks] tiles of 64 keys x 128 queries bf16 (16 KiB, each
                        // written by one key-block workgroup and read by one query-block workgroup), Sp = S rounded up to 256.  Inside a
                        // tile the 16-byte chunks (8 queries of one key) are ordered as the dK/dV kernel emits them, so that each of its
@@ -706,7 +705,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq2_kernel(const AttnBwdArgs 
   auto stage = [&](int buf, int t) {
     char* sK = smem + buf * DQ2_STAGE_BYTES;
     char* sD = sK + TILE_BYTES;
-    const char* dt = (const char*)(dbase + ((a.probe & 1) ? 0 : t) * dtile) + lane * 16;
+    const char* dt = (const char*)(dbase + t * dtile) + lane * 16;
 #pragma unroll
     for (int i = 0; i < 4; ++i) __builtin_amdgcn_global_load_lds((gbl_void*)(dt + (i * 8 + wave) * 1024), (lds_void*)(sD + (i * 8 + wave) * 1024), 16, 0, 0);
     if (t * BKV + BKV <= a.S) {
@@ -766,7 +765,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq2_kernel(const AttnBwdArgs 
     }
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (mine(tq[0]) && !(a.probe & 2)) {
+    if (mine(tq[0])) {
       // 4 k-steps of 16 keys: the 10 transposed reads (dS^T fragment + 4 K^T fragments, lo / hi halves) of step ks+1 are in flight
       // while the 4 MFMAs of step ks run
       const uint32_t so = sbase + cur * DQ2_STAGE_BYTES;
@@ -945,7 +944,6 @@ extern "C" int llx_attn_bwd(const void* q, int64_t q_sb, int64_t q_ss, const voi
   a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.o = (const bf16_t*)o; a.d_o = (const bf16_t*)d_o;
   a.lse = lse; a.delta = delta; a.nlse = delta + B * H * S; a.stamps = nullptr; a.rope = rope; a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk; a.dv = (bf16_t*)dv;
   a.ds = (bf16_t*)ds; a.Sp = (int)(cdiv64(S, 256) * 256);
-  { static int probe = -1; if (probe < 0) { const char* e = getenv("LLX_DQ2_PROBE"); probe = e ? atoi(e) : 0; } a.probe = probe; }
   a.q_sb = q_sb; a.q_ss = q_ss; a.k_sb = k_sb; a.k_ss = k_ss; a.v_sb = v_sb; a.v_ss = v_ss; a.o_sb = o_sb; a.o_ss = o_ss;
   a.do_sb = do_sb; a.do_ss = do_ss; a.dq_sb = dq_sb; a.dq_ss = dq_ss; a.dk_sb = dk_sb; a.dk_ss = dk_ss; a.dv_sb = dv_sb; a.dv_ss = dv_ss;
   a.doc_ids = doc_ids; a.prefix_len = prefix_len; a.flags = (doc_ids || prefix_len) ? (const uint8_t*)flags : nullptr;
