@@ -37,6 +37,9 @@ __global__ __launch_bounds__(SNT_WAVES * 64) void skinny_nt_kernel(const bf16_t*
                                                                    int64_t ldw, bf16_t* __restrict__ out, int M, int K, int R, SkinnyRanges kr,
                                                                    const bf16_t* __restrict__ cs = nullptr, bf16_t* __restrict__ G = nullptr,
                                                                    int64_t ldg = 0) {
+  // loads in flight per wave and round: 8 k-steps; 4 with four row blocks (8 spilled in the block-diagonal form: 256 registers + scratch;
+  // the dense form follows so that both sum in the same order - the ranged product is bit-identical to the dense one)
+  constexpr int SNT_UNROLL_ = NB == 4 ? 4 : SNT_UNROLL;
   __shared__ float part[SNT_WAVES][16][SK_PAD];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int m0 = blockIdx.x * 16;
@@ -53,34 +56,34 @@ __global__ __launch_bounds__(SNT_WAVES * 64) void skinny_nt_kernel(const bf16_t*
   // contiguous bytes per lane and whole 128-byte lines per row and wave (with the natural map, k = 32*step + 8*fq, a wave
   // touches half of every line it reads and the L2 -> L1 traffic of the W fragments doubles).
   const int npairs = K >> 6;
-  const int rounds = npairs / ((SNT_UNROLL / 2) * SNT_WAVES);  // the same trip count for every wave
+  const int rounds = npairs / ((SNT_UNROLL_ / 2) * SNT_WAVES);  // the same trip count for every wave
   // every block walks the same W; starting each block at its own round spreads the simultaneous W reads of an XCD's 32
   // blocks over the L2 channels instead of queueing them on the same lines (that queue was 55 % of the K = 28672 call)
   const int rot = rounds > 0 ? (int)((blockIdx.x * 7u + (blockIdx.x >> 3)) % (unsigned)rounds) : 0;
   for (int it0 = 0; it0 < rounds; ++it0) {
     const int it = (it0 + rot < rounds) ? it0 + rot : it0 + rot - rounds;
-    const int pr = it * (SNT_UNROLL / 2) * SNT_WAVES + wave;
-    bf16x8_t a[SNT_UNROLL], b[SNT_UNROLL][NB];
+    const int pr = it * (SNT_UNROLL_ / 2) * SNT_WAVES + wave;
+    bf16x8_t a[SNT_UNROLL_], b[SNT_UNROLL_][NB];
 #pragma unroll
-    for (int u = 0; u < SNT_UNROLL; ++u) a[u] = *reinterpret_cast<const bf16x8_t*>(xrow + (pr + (u >> 1) * SNT_WAVES) * 64 + 16 * fq + 8 * (u & 1));
+    for (int u = 0; u < SNT_UNROLL_; ++u) a[u] = *reinterpret_cast<const bf16x8_t*>(xrow + (pr + (u >> 1) * SNT_WAVES) * 64 + 16 * fq + 8 * (u & 1));
     if constexpr (SCALE) {
       if (m0 + fr < M) {
 #pragma unroll
-        for (int u = 0; u < SNT_UNROLL; ++u) {
+        for (int u = 0; u < SNT_UNROLL_; ++u) {
           const int k = (pr + (u >> 1) * SNT_WAVES) * 64 + 16 * fq + 8 * (u & 1);
           snt_scaled_store(a[u], cs + k, G + (int64_t)(m0 + fr) * ldg + k);
         }
       }
     }
 #pragma unroll
-    for (int u = 0; u < SNT_UNROLL; ++u) {
+    for (int u = 0; u < SNT_UNROLL_; ++u) {
       const int k0 = (pr + (u >> 1) * SNT_WAVES) * 64;  // wave-uniform
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb)
         if (!RANGED || (k0 >= kr.lo[nb] && k0 < kr.hi[nb])) b[u][nb] = *reinterpret_cast<const bf16x8_t*>(wrow[nb] + k0 + 16 * fq + 8 * (u & 1));
     }
 #pragma unroll
-    for (int u = 0; u < SNT_UNROLL; ++u) {
+    for (int u = 0; u < SNT_UNROLL_; ++u) {
       const int k0 = (pr + (u >> 1) * SNT_WAVES) * 64;
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb)
@@ -90,7 +93,7 @@ __global__ __launch_bounds__(SNT_WAVES * 64) void skinny_nt_kernel(const bf16_t*
   // remaining k-steps (natural map), 32 k-values each
   const int nks = K >> 5;
   {
-    const int pr_done = rounds * (SNT_UNROLL / 2) * SNT_WAVES;  // pairs [0, pr_done) are finished
+    const int pr_done = rounds * (SNT_UNROLL_ / 2) * SNT_WAVES;  // pairs [0, pr_done) are finished
     for (int ks = 2 * pr_done + wave; ks < nks; ks += SNT_WAVES) {
       const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(xrow + ks * 32 + 8 * fq);
       if constexpr (SCALE) {
@@ -521,6 +524,29 @@ __global__ __launch_bounds__(SNT_WAVES * 64) void rmsnorm_skinny_nt_kernel(const
       }
     }
   }
+  // the norm weight and the adapter fragments of the first RSN_PRE pairs do not depend on the row statistics: their loads go out
+  // BEFORE the cross-wave reduction (behind its barrier they started a second memory round trip after the first had drained)
+  const bf16_t* grow = G + wave * npw * 64 + 16 * fq;
+  const bf16_t* wrow[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) wrow[nb] = W + (int64_t)min(nb * 16 + fr, R - 1) * ldw + wave * npw * 64 + 16 * fq;
+  bf16x8_t gv[RSN_MAXPAIRS][2];
+#pragma unroll
+  for (int p = 0; p < RSN_MAXPAIRS; ++p)
+    if (p < npw) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) gv[p][h] = *reinterpret_cast<const bf16x8_t*>(grow + p * 64 + 8 * h);
+    }
+  constexpr int RSN_PRE = NB == 4 ? 2 : 4;
+  bf16x8_t bpre[RSN_PRE][2][NB];
+#pragma unroll
+  for (int p = 0; p < RSN_PRE; ++p)
+    if (p < npw) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) bpre[p][h][nb] = *reinterpret_cast<const bf16x8_t*>(wrow[nb] + p * 64 + 8 * h);
+    }
   // row sums: across the 4 k-groups of a row (lanes fr + 16*fq), then across the 8 waves
   ss += __shfl_xor(ss, 16, 64);
   ss += __shfl_xor(ss, 32, 64);
@@ -532,11 +558,7 @@ __global__ __launch_bounds__(SNT_WAVES * 64) void rmsnorm_skinny_nt_kernel(const
   const float rstd = rsqrtf(tot / (float)D + eps);
   if (wave == 0 && fq == 0 && m0 + fr < M && rstd_out) rstd_out[m0 + fr] = rstd;
   // normalise in registers (single rounding to bf16), store y, and feed the rounded values to the MFMAs
-  const bf16_t* grow = G + wave * npw * 64 + 16 * fq;
   bf16_t* yrow = Y + (int64_t)row * D + wave * npw * 64 + 16 * fq;
-  const bf16_t* wrow[NB];
-#pragma unroll
-  for (int nb = 0; nb < NB; ++nb) wrow[nb] = W + (int64_t)min(nb * 16 + fr, R - 1) * ldw + wave * npw * 64 + 16 * fq;
   f32x4_t acc[NB];
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) acc[nb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -545,14 +567,15 @@ __global__ __launch_bounds__(SNT_WAVES * 64) void rmsnorm_skinny_nt_kernel(const
     if (p < npw) {
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        const bf16x8_t gv = *reinterpret_cast<const bf16x8_t*>(grow + p * 64 + 8 * h);
         bf16x8_t y;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) y[j] = (__bf16)((float)a[p][h][j] * rstd * (float)gv[j]);
+        for (int j = 0; j < 8; ++j) y[j] = (__bf16)((float)a[p][h][j] * rstd * (float)gv[p][h][j]);
         if (m0 + fr < M) *reinterpret_cast<bf16x8_t*>(yrow + p * 64 + 8 * h) = y;
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
-          const bf16x8_t b = *reinterpret_cast<const bf16x8_t*>(wrow[nb] + p * 64 + 8 * h);
+          bf16x8_t b;
+          if (p < RSN_PRE) b = bpre[p < RSN_PRE ? p : 0][h][nb];
+          else b = *reinterpret_cast<const bf16x8_t*>(wrow[nb] + p * 64 + 8 * h);
           acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(y, b, acc[nb], 0, 0, 0);
         }
       }
