@@ -366,7 +366,11 @@ def quantize_int8_rowwise(x: Tensor) -> tuple[Tensor, Tensor]:
 def int8_mm_dequant(a_i8: Tensor, b_i8: Tensor, a_scale: Tensor, b_scale: Tensor) -> Tensor:
     """torchao::int8_mm_dequant (subclasses/int8_mm.py:93-118): int32 accumulate, fp32 row*col scale, cast to the
     scale dtype.  Integer accumulation is order independent => bit-exact target."""
-    acc = a_i8.to(torch.int32) @ b_i8.to(torch.int32)
+    # The integer sum as an fp64 matrix product: every partial sum is an integer below 127^2 * K < 2^53 for any K < 5e11, so fp64
+    # accumulation is exact in any order (the int32 matmul of CPU torch has no BLAS path: minutes at the 8B shapes, seconds this way).
+    K = a_i8.shape[-1]
+    assert 127 * 127 * K < 2 ** 31, "the reference's int32 accumulator would overflow"
+    acc = (a_i8.to(torch.float64) @ b_i8.to(torch.float64)).to(torch.int32)
     out = acc.float() * a_scale.float().view(-1, 1) * b_scale.float().view(1, -1)
     return out.to(a_scale.dtype)
 
