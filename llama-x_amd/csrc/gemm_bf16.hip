@@ -380,6 +380,39 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const GemmArgs g) {
     return;
   }
   // ---- epilogue: acc (C^T fragments: lane owns n = fq*4..+4 for m = frow) -> bf16 -> LDS tile -> coalesced rows.
+  // The operands the epilogue needs from global memory (residual, gate|up, bias, scale, RoPE table) come in batches of EB row pieces,
+  // requested from a clamped - always valid - address with no branch in between (with the load inside the bounds check every piece was
+  // its own basic block: load, s_waitcnt vmcnt(0), store - sixteen exposed latencies per tile).  The FIRST batch is requested here,
+  // before the accumulators go through LDS, and batch b+1 while batch b is combined and stored (two register sets: the accumulators
+  // are dead by then): one exposed latency per tile instead of one per batch (four with the SwiGLU-backward epilogue).
+  constexpr int NIT = BNT / 16;
+  constexpr int EB0 = (EPI == EPI_SWIGLU_BWD || EPI == EPI_ROPE) ? 4 : 8;
+  constexpr int EB = EB0 < NIT / 2 ? EB0 : NIT / 2;  // at least two batches (the half tile has 8 row pieces per thread)
+  constexpr bool AUX = EPI == EPI_RESIDUAL || EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_SWIGLU_BWD || EPI == EPI_ROPE || EPI == EPI_COLSCALE;
+  auto load_aux = [&](int it0, u32x4_t (&aux0)[EB], u32x4_t (&aux1)[EB]) {
+    if constexpr (AUX) {
+#pragma unroll
+      for (int j = 0; j < EB; ++j) {
+        const int q = (it0 + j) * 512 + tid;
+        const int row = q / (BNT / 8), cc = q % (BNT / 8);
+        const int gmc = min(m0 + row, g.M - 1), gnc = min(n0 + cc * 8, g.col_end - 8);
+        if constexpr (EPI == EPI_RESIDUAL) {
+          aux0[j] = *reinterpret_cast<const u32x4_t*>(g.E + (int64_t)gmc * g.lde + gnc);
+        } else if constexpr (EPI == EPI_SWIGLU_BWD) {
+          aux0[j] = *reinterpret_cast<const u32x4_t*>(g.E + (int64_t)gmc * g.lde + gnc);
+          aux1[j] = *reinterpret_cast<const u32x4_t*>(g.E + (int64_t)gmc * g.lde + g.N + gnc);
+        } else if constexpr (EPI == EPI_ROPE) {
+          const float* tp = g.rope + ((int64_t)(gmc % g.rope_S) * 64 + ((gnc & 127) >> 1)) * 2;
+          aux0[j] = *reinterpret_cast<const u32x4_t*>(tp);
+          aux1[j] = *reinterpret_cast<const u32x4_t*>(tp + 4);
+        } else {  // bias / column scale: E[N]
+          aux0[j] = *reinterpret_cast<const u32x4_t*>(g.E + gnc);
+        }
+      }
+    }
+  };
+  u32x4_t auxA0[EB], auxA1[EB], auxB0[EB], auxB1[EB];
+  if constexpr (!SPLITN) load_aux(0, auxA0, auxA1);
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
     const int m = wm * WR + mi * 16 + frow;
@@ -429,36 +462,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const GemmArgs g) {
     }
     return;
   }
-  // Two phases per batch of iterations: first every operand the epilogue needs from global memory (residual, gate|up, bias, scale,
-  // RoPE table) is requested from a clamped - always valid - address, with no branch in between, then the tile rows are read back from
-  // LDS, combined and stored.  With the load inside the bounds check every iteration was its own basic block: load, s_waitcnt vmcnt(0),
-  // store, sixteen times in a row - sixteen exposed memory latencies per tile.
-  constexpr int NIT = BNT / 16;
-  constexpr int EB = (EPI == EPI_SWIGLU_BWD || EPI == EPI_ROPE) ? 4 : 8;
-  constexpr bool AUX = EPI == EPI_RESIDUAL || EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_SWIGLU_BWD || EPI == EPI_ROPE || EPI == EPI_COLSCALE;
-#pragma unroll 1
-  for (int it0 = 0; it0 < NIT; it0 += EB) {
-    u32x4_t aux0[EB], aux1[EB];
-    if constexpr (AUX) {
-#pragma unroll
-      for (int j = 0; j < EB; ++j) {
-        const int q = (it0 + j) * 512 + tid;
-        const int row = q / (BNT / 8), cc = q % (BNT / 8);
-        const int gmc = min(m0 + row, g.M - 1), gnc = min(n0 + cc * 8, g.col_end - 8);
-        if constexpr (EPI == EPI_RESIDUAL) {
-          aux0[j] = *reinterpret_cast<const u32x4_t*>(g.E + (int64_t)gmc * g.lde + gnc);
-        } else if constexpr (EPI == EPI_SWIGLU_BWD) {
-          aux0[j] = *reinterpret_cast<const u32x4_t*>(g.E + (int64_t)gmc * g.lde + gnc);
-          aux1[j] = *reinterpret_cast<const u32x4_t*>(g.E + (int64_t)gmc * g.lde + g.N + gnc);
-        } else if constexpr (EPI == EPI_ROPE) {
-          const float* tp = g.rope + ((int64_t)(gmc % g.rope_S) * 64 + ((gnc & 127) >> 1)) * 2;
-          aux0[j] = *reinterpret_cast<const u32x4_t*>(tp);
-          aux1[j] = *reinterpret_cast<const u32x4_t*>(tp + 4);
-        } else {  // bias / column scale: E[N]
-          aux0[j] = *reinterpret_cast<const u32x4_t*>(g.E + gnc);
-        }
-      }
-    }
+  auto combine = [&](int it0, const u32x4_t (&aux0)[EB], const u32x4_t (&aux1)[EB]) {
 #pragma unroll
     for (int j = 0; j < EB; ++j) {
       const int q = (it0 + j) * 512 + tid;
@@ -502,6 +506,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const GemmArgs g) {
         *reinterpret_cast<u32x4_t*>(g.C + (int64_t)gm * g.ldc + gn) = v;
       }
     }
+  };
+  static_assert((NIT / EB) % 2 == 0, "the batches alternate between two register sets");
+#pragma unroll 1
+  for (int it0 = 0; it0 < NIT; it0 += 2 * EB) {
+    load_aux(it0 + EB, auxB0, auxB1);
+    combine(it0, auxA0, auxA1);
+    if (it0 + 2 * EB < NIT) load_aux(it0 + 2 * EB, auxA0, auxA1);
+    combine(it0 + EB, auxB0, auxB1);
   }
 }
 
