@@ -109,37 +109,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnBwdArgs a
   const int qi = qb * BQ + wave * 32 + r;
   const int qrow = min(qi, a.S - 1);
 
-  bf16x8_t qf[8], dof[8];
-  {
-    const bf16_t* qp = a.q + (int64_t)b * a.q_sb + (int64_t)qrow * a.q_ss + h * HD + 8 * hh;
-    const bf16_t* dp = a.d_o + (int64_t)b * a.do_sb + (int64_t)qrow * a.do_ss + h * HD + 8 * hh;
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
-      qf[ks] = *reinterpret_cast<const bf16x8_t*>(qp + 16 * ks);
-      dof[ks] = *reinterpret_cast<const bf16x8_t*>(dp + 16 * ks);
-    }
-  }
-  const float my_lse = a.lse[((int64_t)b * a.H + h) * a.S + qrow];
-  const float lse_safe = (my_lse == -INFINITY) ? 0.f : my_lse;
-  // delta = rowsum(dO . O): this kernel holds its rows' dO fragments already, so it computes delta itself (half a row per
-  // lane, the partner half-wave holds the other half) and publishes delta and the sanitised -lse for the dK/dV kernel,
-  // which runs after it.  (Replaces a separate pass over O and dO.)
-  float my_delta = 0.f;
-  {
-    const bf16_t* op = a.o + (int64_t)b * a.o_sb + (int64_t)qrow * a.o_ss + h * HD + 8 * hh;
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
-      const bf16x8_t ov = *reinterpret_cast<const bf16x8_t*>(op + 16 * ks);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) my_delta += (float)ov[j] * (float)dof[ks][j];
-    }
-    my_delta += __shfl_xor(my_delta, 32, 64);
-    if (hh == 0 && qi < a.S) {
-      a.delta[((int64_t)b * a.H + h) * a.S + qi] = my_delta;
-      a.nlse[((int64_t)b * a.H + h) * a.S + qi] = -lse_safe;
-    }
-  }
-
   const uint8_t* fl = GENERAL ? a.flags + ((int64_t)b * nqb + qb) * nkt : nullptr;
   const int kt_end = GENERAL ? nkt : min(nkt, (qb * BQ + BQ + BKV - 1) / BKV);
   auto tile_class = [&](int t) -> int {
@@ -206,6 +175,38 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnBwdArgs a
 
   int t = next_tile(0);
   if (t < kt_end) stage(0, t);
+  // (the rows' own operands are requested AFTER the first K/V tile: one memory round trip for both instead of two in a row)
+  bf16x8_t qf[8], dof[8];
+  {
+    const bf16_t* qp = a.q + (int64_t)b * a.q_sb + (int64_t)qrow * a.q_ss + h * HD + 8 * hh;
+    const bf16_t* dp = a.d_o + (int64_t)b * a.do_sb + (int64_t)qrow * a.do_ss + h * HD + 8 * hh;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      qf[ks] = *reinterpret_cast<const bf16x8_t*>(qp + 16 * ks);
+      dof[ks] = *reinterpret_cast<const bf16x8_t*>(dp + 16 * ks);
+    }
+  }
+  const float my_lse = a.lse[((int64_t)b * a.H + h) * a.S + qrow];
+  const float lse_safe = (my_lse == -INFINITY) ? 0.f : my_lse;
+  // delta = rowsum(dO . O): this kernel holds its rows' dO fragments already, so it computes delta itself (half a row per
+  // lane, the partner half-wave holds the other half) and publishes delta and the sanitised -lse for the dK/dV kernel,
+  // which runs after it.  (Replaces a separate pass over O and dO.)
+  float my_delta = 0.f;
+  {
+    const bf16_t* op = a.o + (int64_t)b * a.o_sb + (int64_t)qrow * a.o_ss + h * HD + 8 * hh;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const bf16x8_t ov = *reinterpret_cast<const bf16x8_t*>(op + 16 * ks);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) my_delta += (float)ov[j] * (float)dof[ks][j];
+    }
+    my_delta += __shfl_xor(my_delta, 32, 64);
+    if (hh == 0 && qi < a.S) {
+      a.delta[((int64_t)b * a.H + h) * a.S + qi] = my_delta;
+      a.nlse[((int64_t)b * a.H + h) * a.S + qi] = -lse_safe;
+    }
+  }
+
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   int cur = 0;
