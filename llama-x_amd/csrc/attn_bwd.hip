@@ -111,9 +111,19 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnBwdArgs a
 
   const uint8_t* fl = GENERAL ? a.flags + ((int64_t)b * nqb + qb) * nkt : nullptr;
   const int kt_end = GENERAL ? nkt : min(nkt, (qb * BQ + BQ + BKV - 1) / BKV);
+  // (general masks: the flags of 64 tiles at a time in one register, read by v_readlane - not a dependent byte load per tile)
+  uint32_t fpack = 0;
+  int fchunk = -1;
   auto tile_class = [&](int t) -> int {
-    if constexpr (GENERAL) return fl[t];
-    else return (t * BKV + BKV - 1 <= qb * BQ) ? 2 : 1;
+    if constexpr (GENERAL) {
+      if ((t >> 6) != fchunk) {
+        fchunk = t >> 6;
+        fpack = fl[min(fchunk * 64 + lane, nkt - 1)];
+      }
+      return __builtin_amdgcn_readlane((int)fpack, t & 63);
+    } else {
+      return (t * BKV + BKV - 1 <= qb * BQ) ? 2 : 1;
+    }
   };
   auto next_tile = [&](int t) {
     while (t < kt_end && tile_class(t) == 0) ++t;
@@ -369,9 +379,24 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv3_kernel(const AttnBwdArgs
   const int my_prefix = (GENERAL && a.prefix_len) ? a.prefix_len[b] : 0;
 
   const int qt_first = GENERAL ? 0 : (kblk * DKV2_KEYS) / DKV_QT;
+  // (general masks: the flag bytes of this key block's two tiles for 64 query blocks at a time in one register - lane i holds query
+  // block 64*chunk + i - read by v_readlane; as byte loads they were three dependent memory round trips per query tile)
+  uint32_t fpack = 0;
+  int fchunk = -1;
   auto block_class = [&](int qt, int kt) -> int {
     if (kt >= nkt) return 0;
-    if constexpr (GENERAL) return a.flags[((int64_t)b * nqb + (qt >> 1)) * nkt + kt];
+    if constexpr (GENERAL) {
+      const int qb128 = qt >> 1;
+      if ((qb128 >> 6) != fchunk) {
+        fchunk = qb128 >> 6;
+        uint32_t ln;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
+        const uint8_t* fr = a.flags + ((int64_t)b * nqb + min(fchunk * 64 + (int)ln, nqb - 1)) * nkt;
+        fpack = (uint32_t)fr[2 * kblk] | ((2 * kblk + 1 < nkt ? (uint32_t)fr[2 * kblk + 1] : 0u) << 8);
+      }
+      const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)fpack, qb128 & 63);
+      return (int)((w >> (8 * (kt - 2 * kblk))) & 0xff);
+    }
     const int q_lo = qt * DKV_QT, q_hi = q_lo + DKV_QT - 1, k_lo = kt * BKV, k_hi = k_lo + BKV - 1;
     if (k_lo > q_hi) return 0;
     return (k_hi <= q_lo) ? 2 : 1;
