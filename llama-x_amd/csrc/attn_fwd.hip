@@ -160,6 +160,11 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_kernel(const AttnFwdArgs 
   for (int db = 0; db < 4; ++db) aV[db] = (uint32_t)((4 * hh + tq) * 256 + (((4 * db + 2 * tsub + (tp >> 1)) ^ (tq << 2)) << 4) + ((tp & 1) << 3));
 
   int t = next_tile(0);
+  // document ids of the tile's 64 keys: lane i holds key 64 t + i.  Requested one tile ahead (a coalesced 256-byte load under the tile's
+  // compute) and gathered per element with ds_bpermute - as 32 per-element global loads inside a partly masked tile they put a memory
+  // round trip into every such tile (all of them, with packed documents shorter than a query block).
+  int docv = 0, docv_next = 0;
+  if (GENERAL && docrow && t < kt_end) docv = docrow[min(t * BKV + lane, a.S - 1)];
   if (t < kt_end) stage(0, t);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -179,6 +184,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_kernel(const AttnFwdArgs 
     stamp();  // 0: tile start
     const int tn = next_tile(t + 1);
     if (tn < kt_end) stage(cur ^ 1, tn);
+    if (GENERAL && docrow && tn < kt_end) docv_next = docrow[min(tn * BKV + lane, a.S - 1)];
     const char* sK = smem + cur * ATT_STAGE_BYTES;
     const char* sV = sK + KV_TILE_BYTES;
     const int cls = tile_class(t);
@@ -203,18 +209,21 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_kernel(const AttnFwdArgs 
     // ---- mask, online softmax in log2 units (row statistics are per lane; the partner half-wave holds the other keys)
     float mx = -INFINITY;
     if (cls != 2) {
+      const int kk0 = t * BKV + 4 * hh;  // this lane's first key of the tile; element (kb, e) adds 32 kb + (e & 3) + 8 (e >> 2)
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
+      for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-          const int kk = t * BKV + kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+          const int kk = kk0 + kb * 32 + (e & 3) + 8 * (e >> 2);
           bool ok = (kk < a.S) && (kk <= qi || kk < my_prefix);
           if constexpr (GENERAL) {
-            const int kd = docrow ? docrow[min(kk, a.S - 1)] : my_doc;  // branch-free: one (cached) load per key
+            const int kd = docrow ? __builtin_amdgcn_ds_bpermute((kk - t * BKV) << 2, docv) : my_doc;
             ok = ok && (kd == my_doc);
           }
           st[kb][e] = ok ? st[kb][e] : -INFINITY;
         }
+        if constexpr (GENERAL) __builtin_amdgcn_sched_barrier(0);  // 16 gathered ids at a time, not 32 (registers)
+      }
     }
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
@@ -301,6 +310,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_kernel(const AttnFwdArgs 
     __syncthreads();
     cur ^= 1;
     t = tn;
+    docv = docv_next;
   }
 
   // ---- finalize: O = O^T / l ; lse = m + log2(l)
