@@ -220,9 +220,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnBwdArgs a
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   int cur = 0;
+  // (document masks: the tile's 64 key ids in one register - lane i holds key 64 t + i - requested one tile ahead and gathered by
+  // ds_bpermute, as in the forward kernel)
+  int docv = (GENERAL && docrow && t < kt_end) ? docrow[min(t * BKV + lane, a.S - 1)] : 0, docv_next = 0;
   while (t < kt_end) {
     const int tn = next_tile(t + 1);
     if (tn < kt_end) stage(cur ^ 1, tn);
+    if (GENERAL && docrow && tn < kt_end) docv_next = docrow[min(tn * BKV + lane, a.S - 1)];
     const char* sK = smem + cur * DQ_STAGE_BYTES;
     const char* sV = sK + TILE_BYTES;
     const int cls = tile_class(t);
@@ -243,7 +247,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnBwdArgs a
           const int kk = t * BKV + kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
           bool ok = (kk < a.S) && (kk <= qi || kk < my_prefix);
           if constexpr (GENERAL) {
-            const int kd = docrow ? docrow[min(kk, a.S - 1)] : my_doc;
+            const int kd = docrow ? __builtin_amdgcn_ds_bpermute((kk - t * BKV) << 2, docv) : my_doc;
             ok = ok && (kd == my_doc);
           }
           st[e] = ok ? st[e] : -INFINITY;
@@ -286,6 +290,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnBwdArgs a
     __syncthreads();
     cur ^= 1;
     t = tn;
+    docv = docv_next;
   }
 
   if (qi < a.S) {
@@ -453,6 +458,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv3_kernel(const AttnBwdArgs
     for (int e = 0; e < 16; ++e) { dk[i][e] = 0.f; dv[i][e] = 0.f; }
 
   int qt = next_qt(0);
+  // (document masks: the tile's 64 query-row ids in one register - lane i holds row 64 qt + i - requested one tile ahead, gathered by
+  // ds_bpermute where a partly masked block needs them)
+  int qdoc = 0, qdoc_next = 0;
+  if (GENERAL && docrow && qt < nqt) {
+    uint32_t l0;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l0));
+    qdoc = docrow[min(qt * DKV_QT + (int)l0, a.S - 1)];
+  }
   if (qt < nqt) stage(0, qt);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -487,6 +500,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv3_kernel(const AttnBwdArgs
     int cls = block_class(qt, my_kt);
     if (cls == 2 && (qt * DKV_QT + DKV_QT > a.S)) cls = 1;
     if (have_next) stage(cur ^ 1, qtn);
+    if (GENERAL && docrow && have_next) qdoc_next = docrow[min(qtn * DKV_QT + (int)ln, a.S - 1)];
     stamp();  // 1: next tile's DMA issued
     if (cls != 0) {
       auto rowf = [&](int qb32, int img, int ks) -> bf16x8_t {
@@ -524,7 +538,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv3_kernel(const AttnBwdArgs
             const int qi = qt * DKV_QT + qb32 * 32 + 8 * (e >> 2) + 4 * hh + (e & 3);
             bool ok = (qi < a.S) && (key < a.S) && (key <= qi || key < my_prefix);
             if constexpr (GENERAL) {
-              const int qd = docrow ? docrow[min(qi, a.S - 1)] : key_doc;
+              const int qd = docrow ? __builtin_amdgcn_ds_bpermute((qi - qt * DKV_QT) << 2, qdoc) : key_doc;
               ok = ok && (qd == key_doc);
             }
             st[e] = ok ? st[e] : -INFINITY;
@@ -603,6 +617,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv3_kernel(const AttnBwdArgs
     stamp();  // 9: barrier
     cur ^= 1;
     qt = qtn;
+    qdoc = qdoc_next;
   }
 
   const int64_t plane = (int64_t)a.B * a.S * a.KVH * HD;
