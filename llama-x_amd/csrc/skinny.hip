@@ -41,7 +41,8 @@ __global__ __launch_bounds__(SNT_WAVES * 64) void skinny_nt_kernel(const bf16_t*
   // the dense form follows so that both sum in the same order - the ranged product is bit-identical to the dense one)
   constexpr int SNT_UNROLL_ = NB == 4 ? 4 : SNT_UNROLL;
   __shared__ float part[SNT_WAVES][16][SK_PAD];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform by construction: the k-range tests below become scalar branches
   const int m0 = blockIdx.x * 16;
   const int fr = lane & 15, fq = lane >> 4;
   const bf16_t* xrow = X + (int64_t)min(m0 + fr, M - 1) * ldx;
