@@ -241,15 +241,23 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const GemmArgs g) {
     };
     auto dequant_in_place = [&]() {
       if constexpr (I8) {
+        // the 16 column scales and MI row scales of this lane are requested together, once (as written per accumulator element
+        // they were 128 two-byte loads per lane behind 40-odd s_waitcnt vmcnt(0))
+        float sbv[4][4], rsv[MI];
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) sbv[ni][e] = bf2f(g.sb[col_of(wn * 64 + ni * 16 + fq * 4 + e)]);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) rsv[mi] = bf2f(g.sa[min(m0 + wm * WR + mi * 16 + frow, g.M - 1)]);
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
-          const float rs = bf2f(g.sa[min(m0 + wm * WR + mi * 16 + frow, g.M - 1)]);
+          const float rs = rsv[mi];
 #pragma unroll
           for (int ni = 0; ni < 4; ++ni) {
-            const int n = wn * 64 + ni * 16 + fq * 4;
             f32x4_t cf;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) cf[e] = bf2f(f2bf(((float)acc[mi][ni][e] * rs) * bf2f(g.sb[col_of(n + e)])));
+            for (int e = 0; e < 4; ++e) cf[e] = bf2f(f2bf(((float)acc[mi][ni][e] * rs) * sbv[ni][e]));
             acc[mi][ni] = __builtin_bit_cast(acc_t, cf);
           }
         }
@@ -413,11 +421,22 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const GemmArgs g) {
   };
   u32x4_t auxA0[EB], auxA1[EB], auxB0[EB], auxB1[EB];
   if constexpr (!SPLITN) load_aux(0, auxA0, auxA1);
+  float sbv[4][4], rsv[MI];  // int8 without K-extension: this lane's 16 column scales and MI row scales, requested together
+  if constexpr (I8) {
+    if (g.K2 <= 0) {
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sbv[ni][e] = bf2f(g.sb[col_of(wn * 64 + ni * 16 + fq * 4 + e)]);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) rsv[mi] = bf2f(g.sa[min(m0 + wm * WR + mi * 16 + frow, g.M - 1)]);  // A_scale_rowwise[m]
+    }
+  }
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
     const int m = wm * WR + mi * 16 + frow;
     float rs = 1.f;
-    if constexpr (I8) rs = bf2f(g.sa[min(m0 + m, g.M - 1)]);  // A_scale_rowwise[m]
+    if constexpr (I8) rs = rsv[mi];
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
       const int n = wn * 64 + ni * 16 + fq * 4;
@@ -430,7 +449,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const GemmArgs g) {
         } else {
           // acc.to(fp32) * a_scale * b_scale, one rounding to the scale dtype (subclasses/int8_mm.py:112-118)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) c[e] = ((float)acc[mi][ni][e] * rs) * bf2f(g.sb[col_of(n + e)]);
+          for (int e = 0; e < 4; ++e) c[e] = ((float)acc[mi][ni][e] * rs) * sbv[ni][e];
         }
       } else {
 #pragma unroll

@@ -21,6 +21,7 @@ def bench(name, fn, flops):
     for it in range(16):
         for n, lib in libs.items():
             K._lib = lambda lib=lib: lib
+            L.load = lambda lib=lib: lib  # subclasses.int8_mm goes through L.load()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(); o = fn(); e1.record(); torch.cuda.synchronize()
             times[n].append(e0.elapsed_time(e1) * 1e3); outs[n] = o
@@ -41,3 +42,14 @@ if what in ("bf16", "all"):
     bench("plain 4096x6144x4096", lambda: K.gemm_nt(x, wqkv), 2.0 * M * 6144 * D)
     w13 = rn(2 * I, D); hh = torch.empty(M, I, device=dev, dtype=torch.bfloat16)
     bench("gate|up + SwiGLU forward (EPI 7) 4096x28672x4096", lambda: K.gemm_nt(x, w13, epilogue=K.EPI_SWIGLU_FWD, e=hh), 2.0 * M * 2 * I * D)
+if what in ("i8", "all"):
+    from subclasses.int8_mm import _launch as i8_gemm
+    ri = lambda *s: torch.randint(-127, 128, s, device=dev, generator=g, dtype=torch.int8)
+    xi = ri(M, D); xs = (torch.rand(M, device=dev, generator=g) * 0.02).bfloat16()
+    for name, N, epi in (("int8_mm_dequant 4096x4096x4096", D, 0), ("int8 gate|up + LoRA ext + SwiGLU (EPI 7) 4096x28672x4096", 2 * I, 7),
+                         ("int8 q|k|v + LoRA ext 4096x6144x4096", 6144, 0), ("int8 wo + LoRA ext + residual (EPI 1)", D, 1)):
+        w = ri(N, D); ws = (torch.rand(N, device=dev, generator=g) * 0.02).bfloat16()
+        a2 = rn(M, 64) if "LoRA" in name else None
+        b2 = rn(N, 64) if "LoRA" in name else None
+        e = torch.empty(M, N // 2, device=dev, dtype=torch.bfloat16) if epi == 7 else (rn(M, N) if epi == 1 else None)
+        bench(name, lambda: i8_gemm(xi, w, xs, ws, a2=a2, b2=b2, epilogue=epi, e=e), 2.0 * M * N * D)
