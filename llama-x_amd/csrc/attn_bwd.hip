@@ -186,29 +186,31 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnBwdArgs a
   int t = next_tile(0);
   if (t < kt_end) stage(0, t);
   // (the rows' own operands are requested AFTER the first K/V tile: one memory round trip for both instead of two in a row)
-  bf16x8_t qf[8], dof[8];
+  // q, dO, O and lse of the rows are requested in ONE batch (hipcc put a full wait between the q / dO loads and the lse / O loads)
+  bf16x8_t qf[8], dof[8], ovf[8];
+  const float my_lse = a.lse[((int64_t)b * a.H + h) * a.S + qrow];
   {
     const bf16_t* qp = a.q + (int64_t)b * a.q_sb + (int64_t)qrow * a.q_ss + h * HD + 8 * hh;
     const bf16_t* dp = a.d_o + (int64_t)b * a.do_sb + (int64_t)qrow * a.do_ss + h * HD + 8 * hh;
+    const bf16_t* op = a.o + (int64_t)b * a.o_sb + (int64_t)qrow * a.o_ss + h * HD + 8 * hh;
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
-      qf[ks] = *reinterpret_cast<const bf16x8_t*>(qp + 16 * ks);
+      ovf[ks] = *reinterpret_cast<const bf16x8_t*>(op + 16 * ks);
       dof[ks] = *reinterpret_cast<const bf16x8_t*>(dp + 16 * ks);
+      qf[ks] = *reinterpret_cast<const bf16x8_t*>(qp + 16 * ks);
     }
+    __builtin_amdgcn_sched_barrier(0);
   }
-  const float my_lse = a.lse[((int64_t)b * a.H + h) * a.S + qrow];
   const float lse_safe = (my_lse == -INFINITY) ? 0.f : my_lse;
   // delta = rowsum(dO . O): this kernel holds its rows' dO fragments already, so it computes delta itself (half a row per
   // lane, the partner half-wave holds the other half) and publishes delta and the sanitised -lse for the dK/dV kernel,
   // which runs after it.  (Replaces a separate pass over O and dO.)
   float my_delta = 0.f;
   {
-    const bf16_t* op = a.o + (int64_t)b * a.o_sb + (int64_t)qrow * a.o_ss + h * HD + 8 * hh;
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
-      const bf16x8_t ov = *reinterpret_cast<const bf16x8_t*>(op + 16 * ks);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) my_delta += (float)ov[j] * (float)dof[ks][j];
+      for (int j = 0; j < 8; ++j) my_delta += (float)ovf[ks][j] * (float)dof[ks][j];
     }
     my_delta += __shfl_xor(my_delta, 32, 64);
     if (hh == 0 && qi < a.S) {
