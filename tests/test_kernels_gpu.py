@@ -452,6 +452,30 @@ def test_attention_fwd_bwd(K, cuda, B, S, H, KVH, kind):
     torch.testing.assert_close(dv.cpu().float(), vr.grad, atol=4e-2, rtol=4e-2)
 
 
+@pytest.mark.parametrize("S", [4160, 16384 + 192])
+def test_attention_general_mask_paths_equal_the_causal_kernels_at_long_sequences(K, cuda, S):
+    """The mask-metadata kernels keep a tile's class flags 64 tiles (forward, dQ) / 64 query blocks (dK/dV) at a time in one register and
+    reload at the chunk boundaries; beyond 64 x 64 keys (resp. 64 x 128 rows) that reload is live.  A MaskSpec that encodes the plain
+    causal mask (one document, prefix 0) must then give what the index-arithmetic causal kernels give: same tiles, same classes, same
+    arithmetic - bit for bit - at sizes where the CPU oracle would take minutes."""
+    B, H, KVH = 1, 2, 1
+    q = _bf(O.randn("gq", (B, S, H, 128))).to(cuda)
+    k = _bf(O.randn("gk", (B, S, KVH, 128))).to(cuda)
+    v = _bf(O.randn("gv", (B, S, KVH, 128))).to(cuda)
+    do = _bf(O.randn("gdo", (B, S, H, 128))).to(cuda)
+    o0, lse0 = K.attn_fwd(q, k, v)
+    g0 = [torch.empty_like(t) for t in (q, k, v)]
+    K.attn_bwd(q, k, v, o0, do, lse0, *g0)
+    for ms in (K.MaskSpec(doc_ids=torch.zeros(B, S, device=cuda, dtype=torch.int32)),
+               K.MaskSpec(prefix_len=torch.zeros(B, device=cuda, dtype=torch.int32))):
+        o1, lse1 = K.attn_fwd(q, k, v, ms)
+        assert torch.equal(o0, o1) and torch.equal(lse0, lse1)
+        g1 = [torch.empty_like(t) for t in (q, k, v)]
+        K.attn_bwd(q, k, v, o0, do, lse0, *g1, ms)
+        for a_, b_ in zip(g0, g1):
+            assert torch.equal(a_, b_)
+
+
 def test_attention_random_shapes(K, cuda):
     """Seeded sweep of sequence lengths that are not tile multiples, batch sizes, GQA ratios and mask kinds against the oracle's
     dense-mask attention (evaluated in fp32 on the device through the oracle's own function)."""
