@@ -27,7 +27,7 @@ extern "C" {
 typedef void* llx_stream_t; /* hipStream_t */
 
 /* ---- library ------------------------------------------------------------------------------------------------ */
-int llx_version(void);                                   /* 103 = 0.1.3 */
+int llx_version(void);                                   /* 104 = 0.1.4 */
 const char* llx_last_error_string(void);                 /* thread-local, valid until the next failing call */
 int llx_device_info(int device, char* name, int len);    /* returns CU count, fills gcn arch name */
 
@@ -234,6 +234,15 @@ int llx_skinny_tn_partial(const void* U, const void* Y, int64_t ldy, int64_t M, 
 /* first stage of up to 4 products in ONE launch (the d lora_b and d lora_a products of a linear group: different operands, ready together) */
 int llx_skinny_tn_partial_many(int n, const void* const* U, const void* const* Y, const int64_t* ldy, const int64_t* M, const int64_t* N,
                                const int64_t* R, void* const* workspaces, const int32_t* const* segs, const int* seg_count, llx_stream_t s);
+/* ... where product i with upart[i] != NULL also emits, from the Y tiles it stages anyway, the column-tile partial sums of  u = Y_i . Bt_i^T
+ * (the adapter's dy @ B of modelling/lora.py:43's backward; Bt_i [R_i, N_i] bf16 row-major with row stride ldb[i], the batched
+ * block-diagonal B^T of a fused group; upart[i]: llx_skinny_u_workspace_bytes(M_i, N_i) bytes): dy is read once for dB and u.
+ * llx_skinny_u_reduce sums the tiles into u [M, 64] bf16 (columns >= R zero); segs / seg_count as given to the product. */
+int64_t llx_skinny_u_workspace_bytes(int64_t M, int64_t N);
+int llx_skinny_tn_partial_many_u(int n, const void* const* U, const void* const* Y, const int64_t* ldy, const int64_t* M, const int64_t* N,
+                                 const int64_t* R, void* const* workspaces, const int32_t* const* segs, const int* seg_count,
+                                 const void* const* Bt, const int64_t* ldb, void* const* upart, llx_stream_t s);
+int llx_skinny_u_reduce(const void* upart, void* out, int64_t M, int64_t N, int64_t R, const int32_t* segs, int seg_count, llx_stream_t s);
 int llx_skinny_tn_reduce_many(int n, const void* const* workspaces, void* const* outs, const int64_t* out_ld, const int64_t* M, const int64_t* N,
                               const int64_t* R, const float* scale, const int* transpose_out, const int* accumulate,
                               const int32_t* const* segs, const int* seg_count, llx_stream_t s);

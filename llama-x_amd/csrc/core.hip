@@ -11,7 +11,7 @@ void llx_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
-extern "C" int llx_version(void) { return 103; }  // 0.1.3 (round 3)
+extern "C" int llx_version(void) { return 104; }  // 0.1.4 (round 3)
 
 extern "C" const char* llx_last_error_string(void) { return g_err; }
 

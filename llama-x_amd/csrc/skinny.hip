@@ -205,12 +205,26 @@ struct TnSegs { int n_lo[4], n_hi[4], r_lo[4], r_hi[4]; int64_t off[4]; int coun
 
 // One block of the first stage: column tile `ctile` (256 columns of Y), row range `split`.  NB = 16-row blocks of U^T the registers
 // are sized for; nbl <= NB = the product's own count (layout of its partial array: [split][nbl*16][N]).
+// Bt / upart (nullable): the block ALSO emits partial sums of  Y . Bt^T  (the adapter's  u = dy @ B  - Bt [R rows, N] row-major, the
+// batched block-diagonal B^T of the group) from the Y tile it already has in LDS: upart[ctile][16 rb + j][m] = sum over the tile's 256
+// columns, row block rb handled by wave rb and only where the tile meets the block's column range (the same rb_lo / rb_hi test as the main
+// product).  llx_skinny_u_reduce sums the tiles.  Y is then read ONCE for dB and u instead of once by this kernel and once by skinny_nt.
 template <int NB>
 __device__ __forceinline__ void skinny_tn_block(const bf16_t* __restrict__ U, const bf16_t* __restrict__ Y, int64_t ldy, float* __restrict__ partial,
-                                                int M, int N, int rows_per_split, const TnSegs& sg, int ctile, int split, int nbl, char* sY, char* sU) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+                                                int M, int N, int rows_per_split, const TnSegs& sg, int ctile, int split, int nbl, char* sY, char* sU,
+                                                const bf16_t* __restrict__ Bt = nullptr, int64_t ldb = 0, float* __restrict__ upart = nullptr, int brows = 0) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n0 = ctile * TN_NT;
   const int m_begin = split * rows_per_split, m_end = min(M, m_begin + rows_per_split);
+  // u partials: wave w owns row block w of Bt
+  const bool u_on = upart != nullptr && wave < nbl && n0 + TN_NT > sg.rb_lo[wave] && n0 < sg.rb_hi[wave];  // wave-uniform
+  bf16x8_t ub[8];
+  if (u_on) {
+    const bf16_t* brow = Bt + (int64_t)min(wave * 16 + (lane & 15), brows - 1) * ldb;  // rows past R: their columns of u are zeroed by the reduce
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) ub[ks] = *reinterpret_cast<const bf16x8_t*>(brow + min(n0 + ks * 32 + 8 * (lane >> 4), N - 8));  // columns past N meet zeros of the Y tile
+  }
   f32x4_t acc[NB][4];
 #pragma unroll
   for (int rb = 0; rb < NB; ++rb)
@@ -251,6 +265,26 @@ __device__ __forceinline__ void skinny_tn_block(const bf16_t* __restrict__ U, co
       for (int rb = 0; rb < NB; ++rb)
         if (n0 + TN_NT > sg.rb_lo[rb] && n0 < sg.rb_hi[rb]) acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[rb], b, acc[rb][cb], 0, 0, 0);
     }
+    if (u_on) {  // u partial of this step's 32 rows over the tile's 256 columns: Y rows straight from the row-major LDS tile.
+      // Computed TRANSPOSED (rows of Bt on the accumulator rows, Y rows on the lanes) and stored r-major, upart[tile][r][m]: a store
+      // instruction then writes 64-byte runs of consecutive m and the two row fragments of a step complete whole 128-byte lines
+      // (m-major, 16 of the 64 columns of a row = a quarter line per row, the partial writes doubled the kernel's time).
+#pragma unroll
+      for (int rf = 0; rf < 2; ++rf) {
+        f32x4_t ua0 = {0.f, 0.f, 0.f, 0.f}, ua1 = {0.f, 0.f, 0.f, 0.f};  // two chains: a single one is 8 dependent MFMAs
+        const char* yrow = sY + (rf * 16 + (lane & 15)) * TN_YROW + (lane >> 4) * 16;
+#pragma unroll
+        for (int ks = 0; ks < 8; ks += 2) {
+          ua0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ub[ks], *reinterpret_cast<const bf16x8_t*>(yrow + ks * 64), ua0, 0, 0, 0);
+          ua1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ub[ks + 1], *reinterpret_cast<const bf16x8_t*>(yrow + (ks + 1) * 64), ua1, 0, 0, 0);
+        }
+        const int row = ms + rf * 16 + (lane & 15);
+        if (row < m_end) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) upart[((int64_t)ctile * SK_PAD + wave * 16 + (lane >> 4) * 4 + e) * M + row] = ua0[e] + ua1[e];
+        }
+      }
+    }
   };
   if (m_begin < m_end) load_step(0, m_begin);
   if (m_begin + TN_MS < m_end) load_step(1, m_begin + TN_MS);
@@ -284,16 +318,20 @@ __global__ __launch_bounds__(256) void skinny_tn_kernel(const bf16_t* __restrict
 // together: one ramp-up and one tail instead of two, and the small product's blocks fill the gaps of the big one).  blockIdx.x walks
 // the products' blocks back to back; row blocks past a product's own count are switched off through its rb_lo / rb_hi table.
 #define TN_MANY 4
-struct TnPart { const bf16_t* U; const bf16_t* Y; int64_t ldy; float* partial; int M, N, rows_per_split, ctiles, nblocks, nbl; TnSegs sg; };
+struct TnPart { const bf16_t* U; const bf16_t* Y; int64_t ldy; float* partial; int M, N, rows_per_split, ctiles, nblocks, nbl; TnSegs sg;
+                const bf16_t* Bt; int64_t ldb; float* upart; int brows; };
 struct TnPartMany { TnPart d[TN_MANY]; int n; };
 
+// NB = the largest number of 16-row blocks among the products (accumulator registers: 16 per block; with the u partials' operand
+// fragments on top, four blocks would cost the third resident workgroup per CU)
+template <int NB>
 __global__ __launch_bounds__(256) void skinny_tn_many_kernel(const TnPartMany m) {
   __shared__ __attribute__((aligned(16))) char sY[TN_MS * TN_YROW];
   __shared__ __attribute__((aligned(16))) char sU[TN_MS * TN_UROW];
   int b = blockIdx.x, i = 0;
   while (i < m.n - 1 && b >= m.d[i].nblocks) { b -= m.d[i].nblocks; ++i; }
   const TnPart& d = m.d[i];
-  skinny_tn_block<4>(d.U, d.Y, d.ldy, d.partial, d.M, d.N, d.rows_per_split, d.sg, b % d.ctiles, b / d.ctiles, d.nbl, sY, sU);
+  skinny_tn_block<NB>(d.U, d.Y, d.ldy, d.partial, d.M, d.N, d.rows_per_split, d.sg, b % d.ctiles, b / d.ctiles, d.nbl, sY, sU, d.Bt, d.ldb, d.upart, d.brows);
 }
 
 // (second stage: skinny_tn_reduce_many_kernel below - out = bf16(scale * sum_split partial[split][r][n] (+ out)), plain [R,N] / [N,R] or member segments)
@@ -360,9 +398,20 @@ extern "C" int llx_skinny_tn_partial(const void* U, const void* Y, int64_t ldy, 
 }
 
 // Arrays of length n (<= 4), one entry per product, arguments as llx_skinny_tn_partial.
+extern "C" int llx_skinny_tn_partial_many_u(int n, const void* const* U, const void* const* Y, const int64_t* ldy, const int64_t* M, const int64_t* N,
+                                            const int64_t* R, void* const* workspaces, const int32_t* const* segs, const int* seg_count,
+                                            const void* const* Bt, const int64_t* ldb, void* const* upart, hipStream_t stream);
 extern "C" int llx_skinny_tn_partial_many(int n, const void* const* U, const void* const* Y, const int64_t* ldy, const int64_t* M, const int64_t* N,
                                           const int64_t* R, void* const* workspaces, const int32_t* const* segs, const int* seg_count,
                                           hipStream_t stream) {
+  return llx_skinny_tn_partial_many_u(n, U, Y, ldy, M, N, R, workspaces, segs, seg_count, nullptr, nullptr, nullptr, stream);
+}
+// ... where product i with upart[i] != null ALSO emits the column-tile partials of  Y_i . Bt_i^T  (Bt_i [R_i, N_i] bf16 row-major
+// with row stride ldb[i]; upart[i]: llx_skinny_u_workspace_bytes(M_i, N_i) bytes of fp32 [N_i / 256 tiles][64][M_i]); llx_skinny_u_reduce sums them.
+extern "C" int64_t llx_skinny_u_workspace_bytes(int64_t M, int64_t N) { return cdiv64(N, TN_NT) * M * SK_PAD * 4; }
+extern "C" int llx_skinny_tn_partial_many_u(int n, const void* const* U, const void* const* Y, const int64_t* ldy, const int64_t* M, const int64_t* N,
+                                            const int64_t* R, void* const* workspaces, const int32_t* const* segs, const int* seg_count,
+                                            const void* const* Bt, const int64_t* ldb, void* const* upart, hipStream_t stream) {
   LLX_REQUIRE(n >= 1 && n <= TN_MANY && U && Y && ldy && M && N && R && workspaces && segs && seg_count, "llx_skinny_tn_partial_many: bad arguments (1..4 products)");
   TnPartMany m;
   m.n = n;
@@ -383,10 +432,67 @@ extern "C" int llx_skinny_tn_partial_many(int n, const void* const* U, const voi
     const int rc = tn_fill_segs(d.sg, segs[i], seg_count[i], N[i], R[i], &total);
     if (rc != LLX_OK) return rc;
     for (int rb = d.nbl; rb < 4; ++rb) { d.sg.rb_lo[rb] = d.N; d.sg.rb_hi[rb] = 0; }  // row blocks this product does not have
+    d.Bt = nullptr; d.ldb = 0; d.upart = nullptr; d.brows = (int)R[i];
+    if (upart && upart[i]) {
+      LLX_REQUIRE(Bt && ldb && Bt[i] && ldb[i] % 8 == 0 && (uintptr_t)Bt[i] % 16 == 0 && N[i] >= 8, "llx_skinny_tn_partial_many_u: Bt of product %d", i);
+      d.Bt = (const bf16_t*)Bt[i]; d.ldb = ldb[i]; d.upart = (float*)upart[i];
+    }
     total_blocks += d.nblocks;
   }
-  hipLaunchKernelGGL(skinny_tn_many_kernel, dim3((unsigned)total_blocks), dim3(256), 0, stream, m);
+  int nbmax = 1;
+  for (int i = 0; i < n; ++i) nbmax = m.d[i].nbl > nbmax ? m.d[i].nbl : nbmax;
+  const dim3 grid((unsigned)total_blocks), block(256);
+  if (nbmax == 1) hipLaunchKernelGGL(skinny_tn_many_kernel<1>, grid, block, 0, stream, m);
+  else if (nbmax == 2) hipLaunchKernelGGL(skinny_tn_many_kernel<2>, grid, block, 0, stream, m);
+  else if (nbmax == 3) hipLaunchKernelGGL(skinny_tn_many_kernel<3>, grid, block, 0, stream, m);
+  else hipLaunchKernelGGL(skinny_tn_many_kernel<4>, grid, block, 0, stream, m);
   LLX_LAUNCH_CHECK("llx_skinny_tn_partial_many");
+  return LLX_OK;
+}
+
+// u[m][c] = bf16(sum over the column tiles that meet row block c / 16 of upart[tile][m][c]) for c < R, 0 up to column 64 (the K-extension
+// operand of the data-gradient GEMM and the U operand of the dA product): the second half of the fused dB + u pass.
+__global__ __launch_bounds__(256) void skinny_u_reduce_kernel(const float* __restrict__ upart, bf16_t* __restrict__ out, int M, int R, TnSegs sg) {
+  // block = 64 consecutive rows m x 4 columns, ONE output per thread: thread -> (c = 4 blockIdx.y + (t >> 6), m = 64 blockIdx.x + (t & 63))
+  // reads runs of consecutive m (the partials are r-major); the four columns cross LDS so that u leaves as 8-byte row pieces
+  __shared__ float tile[4][65];
+  const int m0 = blockIdx.x * 64, ml = threadIdx.x & 63, cl = threadIdx.x >> 6;
+  const int c = blockIdx.y * 4 + cl;
+  float sum = 0.f;
+  if (c < R) {
+    const int rb = c >> 4;
+    const int t_lo = sg.rb_lo[rb] / TN_NT, t_hi = (sg.rb_hi[rb] + TN_NT - 1) / TN_NT;
+    const int64_t stride = (int64_t)SK_PAD * M;
+    const float* src = upart + (int64_t)c * M + min(m0 + ml, M - 1);
+    int t = t_lo;
+    for (; t + 8 <= t_hi; t += 8) {  // eight loads in flight, added in tile order
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = src[(t + j) * stride];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) sum += v[j];
+    }
+    for (; t < t_hi; ++t) sum += src[t * stride];
+  }
+  tile[cl][ml] = sum;
+  __syncthreads();
+  if (threadIdx.x < 64 && m0 + threadIdx.x < M) {
+    u32x2_t pk;
+    pk[0] = pack_bf2(tile[0][threadIdx.x], tile[1][threadIdx.x]);
+    pk[1] = pack_bf2(tile[2][threadIdx.x], tile[3][threadIdx.x]);
+    *reinterpret_cast<u32x2_t*>(out + (int64_t)(m0 + threadIdx.x) * SK_PAD + blockIdx.y * 4) = pk;
+  }
+}
+
+// out: [M, 64] bf16.  segs / seg_count as given to the product that filled upart (they define which tiles each 16-column block met).
+extern "C" int llx_skinny_u_reduce(const void* upart, void* out, int64_t M, int64_t N, int64_t R, const int32_t* segs, int seg_count, hipStream_t stream) {
+  LLX_REQUIRE(upart && out && M > 0 && N > 0 && R > 0 && R <= 64, "llx_skinny_u_reduce: bad arguments");
+  TnSegs sg;
+  int64_t total = 0;
+  const int rc = tn_fill_segs(sg, segs, seg_count, N, R, &total);
+  if (rc != LLX_OK) return rc;
+  hipLaunchKernelGGL(skinny_u_reduce_kernel, dim3((unsigned)cdiv64(M, 64), SK_PAD / 4), dim3(256), 0, stream, (const float*)upart, (bf16_t*)out, (int)M, (int)R, sg);
+  LLX_LAUNCH_CHECK("llx_skinny_u_reduce");
   return LLX_OK;
 }
 

@@ -877,14 +877,17 @@ def skinny_nt(x: Tensor, w: Tensor, kranges: Optional[Sequence[int]] = None, col
 
 
 def skinny_tn(u: Tensor, y: Tensor, R: int, scale_: float, out: Tensor, transpose_out: bool, accumulate: bool = False,
-              segs: Optional[Sequence[tuple[int, int, int, int]]] = None, pending: Optional[list] = None, defer: bool = False) -> Tensor:
+              segs: Optional[Sequence[tuple[int, int, int, int]]] = None, pending: Optional[list] = None, defer: bool = False,
+              u_from: Optional[Tensor] = None) -> Tensor:
     """out ([R,N], or [N,R] when transpose_out) (+)= scale * u[:, :R]^T @ y, u [M,64], y [M,N].
     segs: members (n_lo, n_hi, r_lo, r_hi) of a fused group (block-diagonal product): out is then a flat buffer that receives the
     members' [n, r] blocks one after another, each contiguous.
     pending: a list - only the first stage (fp32 split partials) is launched and the second stage is appended to it; ``out`` is valid
     once skinny_tn_flush(pending) has run (one launch for up to 4 products: the adapter gradients of a transformer block).
     defer (with pending): the first stage waits too, until skinny_tn_partials(pending) / the flush launches it together with the other
-    queued products (u and y must stay untouched until then)."""
+    queued products (u and y must stay untouched until then).
+    u_from (with pending, not deferred): the batched B^T image [R, N] of the group - the first stage then also emits the column-tile
+    partials of y @ u_from^T from the y tiles it stages (y is read once for both products); skinny_u_reduce(pending[-1]) finishes it."""
     _chk_bf16(u, y, out)
     M, N = y.shape
     assert u.shape == (M, SK_PAD) and u.is_contiguous() and y.stride(1) == 1 and out.stride(-1) == 1
@@ -901,8 +904,12 @@ def skinny_tn(u: Tensor, y: Tensor, R: int, scale_: float, out: Tensor, transpos
         L.check(_lib().llx_skinny_tn(L.ptr(u), L.ptr(y), y.stride(0), L.ptr(out), out_ld, M, N, R, scale_, int(transpose_out), int(accumulate),
                                      L.ptr(ws), sp, ns, L.stream()), "llx_skinny_tn")
         return out
-    # queued: [ws, out, out_ld, M, N, R, scale, transpose_out, accumulate, segs, n_segs, first stage not launched yet?, u, y]
-    pending.append([ws, out, out_ld, M, N, R, scale_, int(transpose_out), int(accumulate), sp, ns, True, u, y])
+    # queued: [ws, out, out_ld, M, N, R, scale, transpose_out, accumulate, segs, n_segs, first stage not launched yet?, u, y, Bt, upart]
+    upart = None
+    if u_from is not None:
+        assert not defer and u_from.dtype is BF16 and u_from.dim() == 2 and u_from.shape == (R, N) and u_from.stride(1) == 1
+        upart = torch.empty(_lib().llx_skinny_u_workspace_bytes(M, N) // 4, device=y.device, dtype=torch.float32)
+    pending.append([ws, out, out_ld, M, N, R, scale_, int(transpose_out), int(accumulate), sp, ns, True, u, y, u_from, upart])
     if not defer:
         skinny_tn_partials(pending)
     if len(pending) == 4:
@@ -917,7 +924,7 @@ def skinny_tn_partials(pending: list) -> None:
     while todo:
         chunk, todo = todo[:4], todo[4:]
         n = len(chunk)
-        if n == 1:
+        if n == 1 and chunk[0][15] is None:
             c = chunk[0]
             L.check(_lib().llx_skinny_tn_partial(L.ptr(c[12]), L.ptr(c[13]), c[13].stride(0), c[3], c[4], c[5], L.ptr(c[0]), c[9], c[10], L.stream()),
                     "llx_skinny_tn_partial")
@@ -931,10 +938,23 @@ def skinny_tn_partials(pending: list) -> None:
             WS = (ctypes.c_void_p * n)(*[c[0].data_ptr() for c in chunk])
             SG = (ctypes.c_void_p * n)(*[ctypes.cast(c[9], ctypes.c_void_p).value if c[9] is not None else None for c in chunk])
             NS = (ctypes.c_int * n)(*[c[10] for c in chunk])
-            L.check(_lib().llx_skinny_tn_partial_many(n, UU, YY, LY, MM, NN, RR, WS, SG, NS, L.stream()), "llx_skinny_tn_partial_many")
+            BT = (ctypes.c_void_p * n)(*[(c[14].data_ptr() if c[15] is not None else None) for c in chunk])
+            LB = (ctypes.c_int64 * n)(*[(c[14].stride(0) if c[15] is not None else 0) for c in chunk])
+            UP = (ctypes.c_void_p * n)(*[(c[15].data_ptr() if c[15] is not None else None) for c in chunk])
+            L.check(_lib().llx_skinny_tn_partial_many_u(n, UU, YY, LY, MM, NN, RR, WS, SG, NS, BT, LB, UP, L.stream()), "llx_skinny_tn_partial_many")
         for c in chunk:
             c[11] = False
             c[12] = c[13] = None  # the operands are not needed past the first stage
+
+
+def skinny_u_reduce(entry: list) -> Tensor:
+    """u [M, 64] bf16 (= y @ Bt^T, columns >= R zero) from the column-tile partials the first stage of `entry` (a pending item queued with
+    u_from) has written; call it right after that skinny_tn (the partial workspace is reused by the next product of the same parity)."""
+    assert entry[15] is not None and not entry[11], "the product's first stage must have run with u_from"
+    M, N, R = entry[3], entry[4], entry[5]
+    out = torch.empty(M, SK_PAD, device=entry[15].device, dtype=BF16)
+    L.check(_lib().llx_skinny_u_reduce(L.ptr(entry[15]), L.ptr(out), M, N, R, entry[9], entry[10], L.stream()), "llx_skinny_u_reduce")
+    return out
 
 
 def skinny_tn_flush(pending: list) -> None:

@@ -410,6 +410,7 @@ class GroupPlan:
         else:
             t, bT, a2t = saved if saved is not None else (None, None, None)
         u = gA = gBt = None
+        fused_u_here = False
         gB_views: Optional[list[Optional[Tensor]]] = None
         need_a, need_b = self.R > 0 and any(nd[ia] for nd in need), self.R > 0 and any(nd[ia + 1] for nd in need)
         # (issuing the dB chain, the dA chain or both on a side stream - parallel branches of the replayed hipGraph - was measured three
@@ -423,7 +424,16 @@ class GroupPlan:
                 flat = _grad_dst([m.lora_b for m in self.members if m.rank > 0])  # the arena keeps a group's B factors back to back
                 if flat is None:
                     flat = torch.empty(sum((b - a) * (d - c_) for a, b, c_, d in segs), device=dy.device, dtype=BF16)
-                K.skinny_tn(t, dy, self.R, self.scale, flat, transpose_out=True, segs=segs, pending=pending, defer=need_a and _BATCH_TN_PARTIAL)
+                fuse_u = (_FUSE_U and pending is not None and tuple(bT.shape) == (self.R, self.N)
+                          and not (self.int8 and need_dx and _FUSE_DY_SCALE))
+                if fuse_u:
+                    # dB's first stage also emits u = dy @ B from the dy tiles it stages (dy read once instead of twice); the previous
+                    # group's deferred dA stage rides in the same launch
+                    K.skinny_tn(t, dy, self.R, self.scale, flat, transpose_out=True, segs=segs, pending=pending, u_from=bT)
+                    u = K.skinny_u_reduce(pending[-1])
+                    fused_u_here = True
+                else:
+                    K.skinny_tn(t, dy, self.R, self.scale, flat, transpose_out=True, segs=segs, pending=pending, defer=need_a and _BATCH_TN_PARTIAL)
                 gB_views, off = [], 0
                 for m_, (a, b, c_, d) in zip([m for m in self.members if m.rank > 0], segs):
                     gB_views.append(flat[off : off + (b - a) * (d - c_)].view(b - a, d - c_))
@@ -433,7 +443,9 @@ class GroupPlan:
                 K.skinny_tn(t, dy, self.R, self.scale, gBt, transpose_out=True)  # (sliced below: needs the finished product)
         g_scaled = None
         if self.R > 0:  # u = dy.B, then dA = s u^T.x
-            if self.int8 and need_dx and _FUSE_DY_SCALE:
+            if u is not None:
+                pass  # came out of the dB pass above
+            elif self.int8 and need_dx and _FUSE_DY_SCALE:
                 # ... and (dy * scale), the int8 base's data-gradient operand (subclasses/int8.py:127), from the same read of dy
                 u, g_scaled = K.skinny_nt(dy, bT, self._kranges(), colscale=self.scale_cat())
             else:
@@ -442,7 +454,9 @@ class GroupPlan:
                 gA = _grad_dst([m.lora_a for m in self.members if m.rank > 0], (self.R, self.K))  # ... and its A factors
                 if gA is None:
                     gA = torch.empty(self.R, self.K, device=dy.device, dtype=BF16)
-                K.skinny_tn(u, x, self.R, self.scale, gA, transpose_out=False, pending=pending)  # launches the deferred dB stage with its own
+                # (with the fused u the dB stage has run already and dA's first stage launches on its own: batched with the NEXT group's
+                # dB + u stage it made one long launch of unequal blocks - 105 us where the two take 25 + 39)
+                K.skinny_tn(u, x, self.R, self.scale, gA, transpose_out=False, pending=pending)  # otherwise: launches the deferred dB stage with its own
         dx = None
         if need_dx:
             if self.int8:
@@ -703,6 +717,7 @@ _FUSE_SWIGLU_FWD = os.environ.get("LLX_FUSE_SWIGLU_FWD", "1") != "0"  # A/B knob
 _BATCH_TN_REDUCE = os.environ.get("LLX_BATCH_TN_REDUCE", "1") != "0"  # A/B knob: 0 = every adapter-gradient product reduces its partials at once
 _FUSE_NORM_SKINNY = os.environ.get("LLX_FUSE_NORM_SKINNY", "1") != "0"  # A/B knob: 0 = RMSNorm, then the stand-alone skinny product
 _FUSE_DY_SCALE = os.environ.get("LLX_FUSE_DY_SCALE", "1") != "0"  # A/B knob: 0 = stand-alone dy * scale pass for an int8 base's data gradient
+_FUSE_U = os.environ.get("LLX_FUSE_U", "1") != "0"  # A/B knob: 0 = u = dy @ B as its own pass over dy (skinny_nt) instead of riding in dB's first stage
 _BATCH_TN_PARTIAL = os.environ.get("LLX_BATCH_TN_PARTIAL", "1") != "0"  # A/B knob: 0 = dB's first stage launched on its own, before u
 _HEAD_COMPACT = os.environ.get("LLX_HEAD_COMPACT", "1") != "0"  # LM head + loss over the labelled rows only (HeadLossFn)
 # K ranges of the head's d-hidden GEMM (1 = unsplit).  The row count is only known on the device, so the split is static: with 4 ranges

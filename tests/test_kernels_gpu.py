@@ -863,6 +863,41 @@ def test_gemm_tn(K, cuda, M, N1, N2):
     assert torch.equal(c, K.gemm_tn(a, b))
 
 
+@pytest.mark.parametrize("M,Ns,ranks", [(512, (4096, 1024, 1024), (16, 16, 16)), (300, (512, 768), (8, 24)), (4096, (4096,), (16,)), (77, (256, 256), (16, 16))])
+def test_adapter_u_rides_in_the_db_first_stage(K, cuda, M, Ns, ranks):
+    """llx_skinny_tn_partial_many_u + llx_skinny_u_reduce: the first stage of dB = s t^T.dy also emits the column-tile partials of
+    u = dy @ B (modelling/lora.py:43's backward) from the dy tiles it stages; u must equal the stand-alone skinny_nt product up to the
+    fp32 summation order (one bf16 ulp), columns >= R zero, dB itself unchanged bit for bit, and a rerun bit-identical."""
+    N, R = sum(Ns), sum(ranks)
+    bT = torch.zeros(R, N, dtype=torch.bfloat16)
+    segs, ro, no = [], 0, 0
+    for n, r in zip(Ns, ranks):
+        bT[ro : ro + r, no : no + n] = _bf(O.randn(f"ub{no}", (r, n), 0.05))
+        segs.append((no, no + n, ro, ro + r))
+        ro += r; no += n
+    bT = bT.to(cuda)
+    dy = _bf(O.randn("udy", (M, N))).to(cuda)
+    t = torch.zeros(M, 64, dtype=torch.bfloat16)
+    t[:, :R] = _bf(O.randn("ut", (M, R)))
+    t = t.to(cuda)
+    size = sum((b - a) * (d - c) for a, b, c, d in segs)
+    outs = []
+    for fused in (False, True, True):
+        flat = torch.empty(size, device=cuda, dtype=torch.bfloat16)
+        pend = []
+        K.skinny_tn(t, dy, R, 0.5, flat, transpose_out=True, segs=segs, pending=pend, u_from=bT if fused else None)
+        u = K.skinny_u_reduce(pend[-1]) if fused else None
+        K.skinny_tn_flush(pend)
+        outs.append((flat, u))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[1][0], outs[2][0]) and torch.equal(outs[1][1], outs[2][1])
+    u = outs[1][1]
+    assert u.shape == (M, 64) and (u[:, R:] == 0).all()
+    ref = dy.float() @ bT.float().T
+    torch.testing.assert_close(u[:, :R].float(), ref, atol=2 ** -7 * ref.abs().max().item(), rtol=2 ** -7)
+    ref_k = K.skinny_nt(dy, bT)
+    assert (u[:, :R].float() - ref_k[:, :R].float()).abs().max().item() <= 2 ** -7 * ref.abs().max().item()
+
+
 @pytest.mark.parametrize("rows", [0, 1, 63, 64, 200, 333, 1000])
 def test_gemm_tn_device_row_count(K, cuda, rows):
     """llx_gemm_tn_bf16_rows: the contraction stops at min(M, *m_valid) rows read from device memory (the LM head's weight gradient over
