@@ -27,7 +27,7 @@ extern "C" {
 typedef void* llx_stream_t; /* hipStream_t */
 
 /* ---- library ------------------------------------------------------------------------------------------------ */
-int llx_version(void);                                   /* 104 = 0.1.4 */
+int llx_version(void);                                   /* 105 = 0.1.5 */
 const char* llx_last_error_string(void);                 /* thread-local, valid until the next failing call */
 int llx_device_info(int device, char* name, int len);    /* returns CU count, fills gcn arch name */
 
@@ -243,6 +243,12 @@ int llx_skinny_tn_partial_many_u(int n, const void* const* U, const void* const*
                                  const int64_t* R, void* const* workspaces, const int32_t* const* segs, const int* seg_count,
                                  const void* const* Bt, const int64_t* ldb, void* const* upart, llx_stream_t s);
 int llx_skinny_u_reduce(const void* upart, void* out, int64_t M, int64_t N, int64_t R, const int32_t* segs, int seg_count, llx_stream_t s);
+/* ... and product i with G[i] != NULL also writes G_i[m, n] = bf16(Y_i[m, n] * colscale_i[n]) (row stride ldg[i]): the (grad_output * scale)
+ * operand of an int8 linear's data gradient (subclasses/int8.py:127) from the same read of dy. */
+int llx_skinny_tn_partial_many_us(int n, const void* const* U, const void* const* Y, const int64_t* ldy, const int64_t* M, const int64_t* N,
+                                  const int64_t* R, void* const* workspaces, const int32_t* const* segs, const int* seg_count,
+                                  const void* const* Bt, const int64_t* ldb, void* const* upart, const void* const* colscale,
+                                  void* const* G, const int64_t* ldg, llx_stream_t s);
 int llx_skinny_tn_reduce_many(int n, const void* const* workspaces, void* const* outs, const int64_t* out_ld, const int64_t* M, const int64_t* N,
                               const int64_t* R, const float* scale, const int* transpose_out, const int* accumulate,
                               const int32_t* const* segs, const int* seg_count, llx_stream_t s);

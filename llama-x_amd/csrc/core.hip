@@ -11,7 +11,7 @@ void llx_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
-extern "C" int llx_version(void) { return 104; }  // 0.1.4 (round 3)
+extern "C" int llx_version(void) { return 105; }  // 0.1.5 (round 3)
 
 extern "C" const char* llx_last_error_string(void) { return g_err; }
 

@@ -212,7 +212,8 @@ struct TnSegs { int n_lo[4], n_hi[4], r_lo[4], r_hi[4]; int64_t off[4]; int coun
 template <int NB>
 __device__ __forceinline__ void skinny_tn_block(const bf16_t* __restrict__ U, const bf16_t* __restrict__ Y, int64_t ldy, float* __restrict__ partial,
                                                 int M, int N, int rows_per_split, const TnSegs& sg, int ctile, int split, int nbl, char* sY, char* sU,
-                                                const bf16_t* __restrict__ Bt = nullptr, int64_t ldb = 0, float* __restrict__ upart = nullptr, int brows = 0) {
+                                                const bf16_t* __restrict__ Bt = nullptr, int64_t ldb = 0, float* __restrict__ upart = nullptr, int brows = 0,
+                                                const bf16_t* __restrict__ cs = nullptr, bf16_t* __restrict__ G = nullptr, int64_t ldg = 0) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n0 = ctile * TN_NT;
@@ -251,6 +252,17 @@ __device__ __forceinline__ void skinny_tn_block(const bf16_t* __restrict__ U, co
     for (int i = 0; i < 4; ++i) {
       const int q = i * 256 + tid;
       *reinterpret_cast<u32x4_t*>(sY + (q >> 5) * TN_YROW + (q & 31) * 16) = yv[set][i];
+      if (G) {  // the (grad_output * scale) operand of a weight-only / dynamic int8 linear's data gradient (subclasses/int8.py:127) from
+                // the same read of dy: every element of Y passes through exactly one block of the first stage
+        const int row = ms + (q >> 5), col = n0 + (q & 31) * 8;
+        if (row < m_end && col < N) {
+          const u32x4_t c = *reinterpret_cast<const u32x4_t*>(cs + col);
+          u32x4_t o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = pack_bf2(bflo(yv[set][i][e]) * bflo(c[e]), bfhi(yv[set][i][e]) * bfhi(c[e]));
+          *reinterpret_cast<u32x4_t*>(G + (int64_t)row * ldg + col) = o;
+        }
+      }
     }
     *reinterpret_cast<u32x4_t*>(sU + (tid >> 3) * TN_UROW + (tid & 7) * 16) = uv[set];
     __syncthreads();
@@ -319,7 +331,7 @@ __global__ __launch_bounds__(256) void skinny_tn_kernel(const bf16_t* __restrict
 // the products' blocks back to back; row blocks past a product's own count are switched off through its rb_lo / rb_hi table.
 #define TN_MANY 4
 struct TnPart { const bf16_t* U; const bf16_t* Y; int64_t ldy; float* partial; int M, N, rows_per_split, ctiles, nblocks, nbl; TnSegs sg;
-                const bf16_t* Bt; int64_t ldb; float* upart; int brows; };
+                const bf16_t* Bt; int64_t ldb; float* upart; int brows; const bf16_t* cs; bf16_t* G; int64_t ldg; };
 struct TnPartMany { TnPart d[TN_MANY]; int n; };
 
 // NB = the largest number of 16-row blocks among the products (accumulator registers: 16 per block; with the u partials' operand
@@ -331,7 +343,7 @@ __global__ __launch_bounds__(256) void skinny_tn_many_kernel(const TnPartMany m)
   int b = blockIdx.x, i = 0;
   while (i < m.n - 1 && b >= m.d[i].nblocks) { b -= m.d[i].nblocks; ++i; }
   const TnPart& d = m.d[i];
-  skinny_tn_block<NB>(d.U, d.Y, d.ldy, d.partial, d.M, d.N, d.rows_per_split, d.sg, b % d.ctiles, b / d.ctiles, d.nbl, sY, sU, d.Bt, d.ldb, d.upart, d.brows);
+  skinny_tn_block<NB>(d.U, d.Y, d.ldy, d.partial, d.M, d.N, d.rows_per_split, d.sg, b % d.ctiles, b / d.ctiles, d.nbl, sY, sU, d.Bt, d.ldb, d.upart, d.brows, d.cs, d.G, d.ldg);
 }
 
 // (second stage: skinny_tn_reduce_many_kernel below - out = bf16(scale * sum_split partial[split][r][n] (+ out)), plain [R,N] / [N,R] or member segments)
@@ -409,9 +421,21 @@ extern "C" int llx_skinny_tn_partial_many(int n, const void* const* U, const voi
 // ... where product i with upart[i] != null ALSO emits the column-tile partials of  Y_i . Bt_i^T  (Bt_i [R_i, N_i] bf16 row-major
 // with row stride ldb[i]; upart[i]: llx_skinny_u_workspace_bytes(M_i, N_i) bytes of fp32 [N_i / 256 tiles][64][M_i]); llx_skinny_u_reduce sums them.
 extern "C" int64_t llx_skinny_u_workspace_bytes(int64_t M, int64_t N) { return cdiv64(N, TN_NT) * M * SK_PAD * 4; }
+extern "C" int llx_skinny_tn_partial_many_us(int n, const void* const* U, const void* const* Y, const int64_t* ldy, const int64_t* M, const int64_t* N,
+                                             const int64_t* R, void* const* workspaces, const int32_t* const* segs, const int* seg_count,
+                                             const void* const* Bt, const int64_t* ldb, void* const* upart, const void* const* colscale,
+                                             void* const* G, const int64_t* ldg, hipStream_t stream);
 extern "C" int llx_skinny_tn_partial_many_u(int n, const void* const* U, const void* const* Y, const int64_t* ldy, const int64_t* M, const int64_t* N,
                                             const int64_t* R, void* const* workspaces, const int32_t* const* segs, const int* seg_count,
                                             const void* const* Bt, const int64_t* ldb, void* const* upart, hipStream_t stream) {
+  return llx_skinny_tn_partial_many_us(n, U, Y, ldy, M, N, R, workspaces, segs, seg_count, Bt, ldb, upart, nullptr, nullptr, nullptr, stream);
+}
+// ... and product i with G[i] != null also writes G_i[m, n] = bf16(Y_i[m, n] * colscale_i[n]) (row stride ldg[i]; colscale bf16 [N_i]): the
+// (grad_output * scale) operand of an int8 linear's data gradient (subclasses/int8.py:127) from the same read of dy.
+extern "C" int llx_skinny_tn_partial_many_us(int n, const void* const* U, const void* const* Y, const int64_t* ldy, const int64_t* M, const int64_t* N,
+                                             const int64_t* R, void* const* workspaces, const int32_t* const* segs, const int* seg_count,
+                                             const void* const* Bt, const int64_t* ldb, void* const* upart, const void* const* colscale,
+                                             void* const* G, const int64_t* ldg, hipStream_t stream) {
   LLX_REQUIRE(n >= 1 && n <= TN_MANY && U && Y && ldy && M && N && R && workspaces && segs && seg_count, "llx_skinny_tn_partial_many: bad arguments (1..4 products)");
   TnPartMany m;
   m.n = n;
@@ -436,6 +460,11 @@ extern "C" int llx_skinny_tn_partial_many_u(int n, const void* const* U, const v
     if (upart && upart[i]) {
       LLX_REQUIRE(Bt && ldb && Bt[i] && ldb[i] % 8 == 0 && (uintptr_t)Bt[i] % 16 == 0 && N[i] >= 8, "llx_skinny_tn_partial_many_u: Bt of product %d", i);
       d.Bt = (const bf16_t*)Bt[i]; d.ldb = ldb[i]; d.upart = (float*)upart[i];
+    }
+    d.cs = nullptr; d.G = nullptr; d.ldg = 0;
+    if (G && G[i]) {
+      LLX_REQUIRE(colscale && ldg && colscale[i] && ldg[i] % 8 == 0 && ((uintptr_t)colscale[i] | (uintptr_t)G[i]) % 16 == 0, "llx_skinny_tn_partial_many_us: scaled copy of product %d", i);
+      d.cs = (const bf16_t*)colscale[i]; d.G = (bf16_t*)G[i]; d.ldg = ldg[i];
     }
     total_blocks += d.nblocks;
   }

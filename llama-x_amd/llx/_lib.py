@@ -85,6 +85,7 @@ SIGNATURES: dict[str, tuple] = {
     "llx_skinny_u_workspace_bytes": (_L, [_L, _L]),
     "llx_skinny_tn_partial_many_u": (c_int, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "llx_skinny_u_reduce": (c_int, [_P, _P, _L, _L, _L, _P, _I, _P]),
+    "llx_skinny_tn_partial_many_us": (c_int, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "llx_skinny_tn_reduce_many": (c_int, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "llx_gemm_nt_bf16": (c_int, [_P, _L, _P, _L, _P, _L, _L, _L, _L, _P, _L, _P, _L, _L, _I, _P, _L, _P]),
     "llx_gemm_nt_bf16_splitk": (c_int, [_P, _L, _P, _L, _P, _L, _L, _L, _I, _P, _P]),

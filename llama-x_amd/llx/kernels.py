@@ -878,7 +878,7 @@ def skinny_nt(x: Tensor, w: Tensor, kranges: Optional[Sequence[int]] = None, col
 
 def skinny_tn(u: Tensor, y: Tensor, R: int, scale_: float, out: Tensor, transpose_out: bool, accumulate: bool = False,
               segs: Optional[Sequence[tuple[int, int, int, int]]] = None, pending: Optional[list] = None, defer: bool = False,
-              u_from: Optional[Tensor] = None) -> Tensor:
+              u_from: Optional[Tensor] = None, scaled: Optional[tuple[Tensor, Tensor]] = None) -> Tensor:
     """out ([R,N], or [N,R] when transpose_out) (+)= scale * u[:, :R]^T @ y, u [M,64], y [M,N].
     segs: members (n_lo, n_hi, r_lo, r_hi) of a fused group (block-diagonal product): out is then a flat buffer that receives the
     members' [n, r] blocks one after another, each contiguous.
@@ -887,7 +887,9 @@ def skinny_tn(u: Tensor, y: Tensor, R: int, scale_: float, out: Tensor, transpos
     defer (with pending): the first stage waits too, until skinny_tn_partials(pending) / the flush launches it together with the other
     queued products (u and y must stay untouched until then).
     u_from (with pending, not deferred): the batched B^T image [R, N] of the group - the first stage then also emits the column-tile
-    partials of y @ u_from^T from the y tiles it stages (y is read once for both products); skinny_u_reduce(pending[-1]) finishes it."""
+    partials of y @ u_from^T from the y tiles it stages (y is read once for both products); skinny_u_reduce(pending[-1]) finishes it.
+    scaled = (colscale [N] bf16, g [M, N] bf16 output; with u_from): the first stage also writes g = bf16(y * colscale) - the scaled
+    gradient an int8 linear's data gradient multiplies (subclasses/int8.py:127)."""
     _chk_bf16(u, y, out)
     M, N = y.shape
     assert u.shape == (M, SK_PAD) and u.is_contiguous() and y.stride(1) == 1 and out.stride(-1) == 1
@@ -909,7 +911,9 @@ def skinny_tn(u: Tensor, y: Tensor, R: int, scale_: float, out: Tensor, transpos
     if u_from is not None:
         assert not defer and u_from.dtype is BF16 and u_from.dim() == 2 and u_from.shape == (R, N) and u_from.stride(1) == 1
         upart = torch.empty(_lib().llx_skinny_u_workspace_bytes(M, N) // 4, device=y.device, dtype=torch.float32)
-    pending.append([ws, out, out_ld, M, N, R, scale_, int(transpose_out), int(accumulate), sp, ns, True, u, y, u_from, upart])
+    if scaled is not None:
+        assert u_from is not None and scaled[0].dtype is BF16 and scaled[0].numel() == N and scaled[1].shape == (M, N) and scaled[1].stride(1) == 1
+    pending.append([ws, out, out_ld, M, N, R, scale_, int(transpose_out), int(accumulate), sp, ns, True, u, y, u_from, upart, scaled])
     if not defer:
         skinny_tn_partials(pending)
     if len(pending) == 4:
@@ -941,7 +945,10 @@ def skinny_tn_partials(pending: list) -> None:
             BT = (ctypes.c_void_p * n)(*[(c[14].data_ptr() if c[15] is not None else None) for c in chunk])
             LB = (ctypes.c_int64 * n)(*[(c[14].stride(0) if c[15] is not None else 0) for c in chunk])
             UP = (ctypes.c_void_p * n)(*[(c[15].data_ptr() if c[15] is not None else None) for c in chunk])
-            L.check(_lib().llx_skinny_tn_partial_many_u(n, UU, YY, LY, MM, NN, RR, WS, SG, NS, BT, LB, UP, L.stream()), "llx_skinny_tn_partial_many")
+            CS = (ctypes.c_void_p * n)(*[(c[16][0].data_ptr() if c[16] is not None else None) for c in chunk])
+            GG = (ctypes.c_void_p * n)(*[(c[16][1].data_ptr() if c[16] is not None else None) for c in chunk])
+            LG = (ctypes.c_int64 * n)(*[(c[16][1].stride(0) if c[16] is not None else 0) for c in chunk])
+            L.check(_lib().llx_skinny_tn_partial_many_us(n, UU, YY, LY, MM, NN, RR, WS, SG, NS, BT, LB, UP, CS, GG, LG, L.stream()), "llx_skinny_tn_partial_many")
         for c in chunk:
             c[11] = False
             c[12] = c[13] = None  # the operands are not needed past the first stage

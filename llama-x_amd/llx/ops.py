@@ -409,7 +409,7 @@ class GroupPlan:
             dy = K.scale(dy_out, colscale=c)
         else:
             t, bT, a2t = saved if saved is not None else (None, None, None)
-        u = gA = gBt = None
+        u = gA = gBt = g_scaled = None
         fused_u_here = False
         gB_views: Optional[list[Optional[Tensor]]] = None
         need_a, need_b = self.R > 0 and any(nd[ia] for nd in need), self.R > 0 and any(nd[ia + 1] for nd in need)
@@ -424,12 +424,15 @@ class GroupPlan:
                 flat = _grad_dst([m.lora_b for m in self.members if m.rank > 0])  # the arena keeps a group's B factors back to back
                 if flat is None:
                     flat = torch.empty(sum((b - a) * (d - c_) for a, b, c_, d in segs), device=dy.device, dtype=BF16)
-                fuse_u = (_FUSE_U and pending is not None and tuple(bT.shape) == (self.R, self.N)
-                          and not (self.int8 and need_dx and _FUSE_DY_SCALE))
+                fuse_u = _FUSE_U and pending is not None and tuple(bT.shape) == (self.R, self.N)
                 if fuse_u:
-                    # dB's first stage also emits u = dy @ B from the dy tiles it stages (dy read once instead of twice); the previous
-                    # group's deferred dA stage rides in the same launch
-                    K.skinny_tn(t, dy, self.R, self.scale, flat, transpose_out=True, segs=segs, pending=pending, u_from=bT)
+                    # dB's first stage also emits u = dy @ B from the dy tiles it stages (dy read once instead of twice) - and, for an
+                    # int8 base, (dy * scale), the operand of its data gradient (subclasses/int8.py:127)
+                    sc = None
+                    if self.int8 and need_dx and _FUSE_DY_SCALE:
+                        g_scaled = torch.empty_like(dy)
+                        sc = (self.scale_cat(), g_scaled)
+                    K.skinny_tn(t, dy, self.R, self.scale, flat, transpose_out=True, segs=segs, pending=pending, u_from=bT, scaled=sc)
                     u = K.skinny_u_reduce(pending[-1])
                     fused_u_here = True
                 else:
@@ -441,7 +444,6 @@ class GroupPlan:
             else:
                 gBt = torch.empty(self.N, self.R, device=dy.device, dtype=BF16)
                 K.skinny_tn(t, dy, self.R, self.scale, gBt, transpose_out=True)  # (sliced below: needs the finished product)
-        g_scaled = None
         if self.R > 0:  # u = dy.B, then dA = s u^T.x
             if u is not None:
                 pass  # came out of the dB pass above

@@ -30,7 +30,7 @@ def test_header_and_library_agree():
         assert hasattr(lib, name) and name in L.DEBUG_SIGNATURES, name
     assert sorted(L.DEBUG_SIGNATURES) == debug
     assert sorted(f for f in os.listdir(os.path.join(ROOT, "include")) if f.endswith(".h")) == ["llx.h", "llx_debug.h"]
-    assert lib.llx_version() == 104
+    assert lib.llx_version() == 105
     assert isinstance(lib.llx_last_error_string(), (bytes, type(None)))
 
 
