@@ -903,6 +903,7 @@ def skinny_tn(u: Tensor, y: Tensor, R: int, scale_: float, out: Tensor, transpos
     ws = torch.empty(_lib().llx_skinny_tn_workspace_bytes(M, N, R), device=y.device, dtype=torch.uint8)
     out_ld = out.stride(0) if out.dim() == 2 else 0
     if pending is None:
+        assert u_from is None and scaled is None, "the fused u / scaled-copy outputs need the queued (pending=) form"
         L.check(_lib().llx_skinny_tn(L.ptr(u), L.ptr(y), y.stride(0), L.ptr(out), out_ld, M, N, R, scale_, int(transpose_out), int(accumulate),
                                      L.ptr(ws), sp, ns, L.stream()), "llx_skinny_tn")
         return out
