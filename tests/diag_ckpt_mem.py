@@ -1,4 +1,5 @@
-"""Diagnostic: which saved activations survive a checkpointed forward (memory after forward / peak, weakrefs of everything _save saw)."""
+"""Diagnostic (test infrastructure - it uses the oracle's seeded initialisers, so it lives under tests/; not collected by pytest): which saved
+activations survive a checkpointed forward (memory after forward / peak, weakrefs of everything _save saw).   python tests/diag_ckpt_mem.py"""
 import gc
 import os
 import sys
