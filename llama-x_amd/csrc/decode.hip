@@ -48,20 +48,24 @@ __device__ __forceinline__ float dot8(const u32x4_t& w, const float (&xf)[8]) {
   return s;
 }
 
-template <int MT, int EPI, bool NORM>
+// RPW output rows per wave at a time (4, or 2 for the narrow projections: twice the waves, each with the same 8 loads in flight, so
+// that 4096 output rows still put 2 workgroups on every CU); a step is 8 / RPW pieces of 512 elements (64 lanes x 8) of those rows.
+template <int MT, int EPI, bool NORM, int RPW = 4>
 __global__ __launch_bounds__(256, 2) void gemv_kernel(const GemvArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int K = a.K;
-  const int nsteps = (K + 1023) >> 10;  // a step = two 512-element pieces (64 lanes x 8) of four weight rows: 8 x 16-byte loads per lane
-  const int Kp = nsteps << 10;          // the LDS copy of x is zero-padded to whole steps: weight lanes past K multiply zeros
+  static_assert(RPW == 4 || (RPW == 2 && EPI != GV_SWIGLU), "rows per wave");
+  constexpr int PIECES = 8 / RPW, STEP = 512 * PIECES;
+  const int nsteps = (K + STEP - 1) / STEP;  // a step = PIECES 512-element pieces of RPW weight rows: 8 x 16-byte loads per lane
+  const int Kp = nsteps * STEP;              // the LDS copy of x is zero-padded to whole steps: weight lanes past K multiply zeros
   bf16_t* xs = reinterpret_cast<bf16_t*>(smem);  // [MT][Kp]
   float* red = reinterpret_cast<float*>(smem + (size_t)MT * Kp * 2);
 
   // ---- row groups: 4 output rows per wave at a time.  SWIGLU: the gate and up rows of two hidden units (W[0] rows 2g, 2g+1 and
   // W[1] rows 2g, 2g+1), so that the epilogue has g and u of one unit side by side.
-  struct Grp { const bf16_t* wr[4]; int row0, seg; };
+  struct Grp { const bf16_t* wr[RPW]; int row0, seg; };
   auto setup = [&](int g, Grp& G) {
     if constexpr (EPI == GV_SWIGLU) {
       const int half = a.N / 2;
@@ -69,25 +73,25 @@ __global__ __launch_bounds__(256, 2) void gemv_kernel(const GemvArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) G.wr[r] = a.W[r >> 1] + (int64_t)min(G.row0 + (r & 1), half - 1) * a.ldw[r >> 1];
     } else {
-      G.row0 = 4 * g;
+      G.row0 = RPW * g;
       G.seg = G.row0 >= a.seg_end[0] ? (G.row0 >= a.seg_end[1] ? 2 : 1) : 0;  // wave-uniform (segment boundaries are multiples of 4)
       const int base = G.seg == 0 ? 0 : a.seg_end[G.seg - 1];
       const int last = a.seg_end[G.seg] - 1 - base;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) G.wr[r] = a.W[G.seg] + (int64_t)min(G.row0 - base + r, last) * a.ldw[G.seg];
+      for (int r = 0; r < RPW; ++r) G.wr[r] = a.W[G.seg] + (int64_t)min(G.row0 - base + r, last) * a.ldw[G.seg];
     }
   };
   auto load_step = [&](u32x4_t (&w)[8], const Grp& G, int s) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int k = (2 * s + j) * 512 + lane * 8;
+    for (int j = 0; j < PIECES; ++j) {
+      const int k = (PIECES * s + j) * 512 + lane * 8;
       const int kk = k < K ? k : 0;  // lanes past the row end re-read its start; their x is zero
 #pragma unroll
-      for (int r = 0; r < 4; ++r) w[4 * j + r] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(G.wr[r] + kk));
+      for (int r = 0; r < RPW; ++r) w[RPW * j + r] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(G.wr[r] + kk));
     }
   };
   const int nwaves = gridDim.x * 4;
-  const int ngroups = EPI == GV_SWIGLU ? (a.N / 2 + 1) / 2 : (a.N + 3) / 4;
+  const int ngroups = EPI == GV_SWIGLU ? (a.N / 2 + 1) / 2 : (a.N + RPW - 1) / RPW;
   int g = blockIdx.x * 4 + wave, s = 0;
   Grp cur, nxt;
   u32x4_t WA[8], WB[8];
@@ -124,15 +128,15 @@ __global__ __launch_bounds__(256, 2) void gemv_kernel(const GemvArgs a) {
   }
   __syncthreads();
 
-  float acc[4][MT];
+  float acc[RPW][MT];
 #pragma unroll
-  for (int r = 0; r < 4; ++r)
+  for (int r = 0; r < RPW; ++r)
 #pragma unroll
     for (int m = 0; m < MT; ++m) acc[r][m] = 0.f;
   auto compute_step = [&](const u32x4_t (&w)[8], int st) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int k = (2 * st + j) * 512 + lane * 8;
+    for (int j = 0; j < PIECES; ++j) {
+      const int k = (PIECES * st + j) * 512 + lane * 8;
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
         const u32x4_t xv = *reinterpret_cast<const u32x4_t*>(xs + (size_t)m * Kp + k);
@@ -140,7 +144,7 @@ __global__ __launch_bounds__(256, 2) void gemv_kernel(const GemvArgs a) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) { xf[2 * e] = bflo(xv[e]); xf[2 * e + 1] = bfhi(xv[e]); }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[r][m] += dot8(w[4 * j + r], xf);
+        for (int r = 0; r < RPW; ++r) acc[r][m] += dot8(w[RPW * j + r], xf);
       }
     }
   };
@@ -148,7 +152,7 @@ __global__ __launch_bounds__(256, 2) void gemv_kernel(const GemvArgs a) {
     const int row0 = G.row0, seg = G.seg;
     // LoRA extension: lanes 0 .. rank/8-1 hold 8 elements of the row's B factor each
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
+    for (int r = 0; r < RPW; ++r) {
       const int s2 = EPI == GV_SWIGLU ? (r >> 1) : seg;
       const bf16_t* bp = a.bext[s2];
       if (bp != nullptr && lane * 8 < a.rank[s2]) {
@@ -171,14 +175,14 @@ __global__ __launch_bounds__(256, 2) void gemv_kernel(const GemvArgs a) {
       }
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+    for (int r = 0; r < RPW; ++r)
 #pragma unroll
       for (int m = 0; m < MT; ++m) acc[r][m] = wave_sum(acc[r][m]);
     // ---- epilogue: lane m writes token m (every lane holds every sum)
     if (lane < MT && lane < a.M) {
-      float v[4];
+      float v[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
+      for (int r = 0; r < RPW; ++r) {
         float sm = acc[r][0];
 #pragma unroll
         for (int m = 1; m < MT; ++m) sm = lane == m ? acc[r][m] : sm;
@@ -202,22 +206,19 @@ __global__ __launch_bounds__(256, 2) void gemv_kernel(const GemvArgs a) {
         const int d = hrow & (HD - 1);
         if (is_q || is_k) {
           const float* tp = a.rope + ((int64_t)m * 64 + (d >> 1)) * 2;
-          const float c0 = tp[0], s0 = tp[1], c1 = tp[2], s1 = tp[3];
+          const float c0 = tp[0], s0 = tp[1], c1 = RPW == 4 ? tp[2] : 1.f, s1 = RPW == 4 ? tp[3] : 0.f;
           const float y0 = v[0] * c0 - v[1] * s0, y1 = v[1] * c0 + v[0] * s0, y2 = v[2] * c1 - v[3] * s1, y3 = v[3] * c1 + v[2] * s1;
           v[0] = y0; v[1] = y1; v[2] = y2; v[3] = y3;
         }
         u32x2_t pk;
         pk[0] = pack_bf2(v[0], v[1]);
         pk[1] = pack_bf2(v[2], v[3]);
-        if (is_q) {
-          *reinterpret_cast<u32x2_t*>(a.out + (int64_t)m * a.ldo + row0) = pk;
-        } else {
-          bf16_t* cache = is_k ? a.kc : a.vc;
-          *reinterpret_cast<u32x2_t*>(cache + (int64_t)(hrow >> 7) * a.c_sh + a.pos[m] * a.c_ss + d) = pk;
-        }
+        bf16_t* dst = is_q ? a.out + (int64_t)m * a.ldo + row0 : (is_k ? a.kc : a.vc) + (int64_t)(hrow >> 7) * a.c_sh + a.pos[m] * a.c_ss + d;
+        if constexpr (RPW == 4) *reinterpret_cast<u32x2_t*>(dst) = pk;
+        else *reinterpret_cast<uint32_t*>(dst) = pk[0];  // one rotation pair
       } else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < RPW; ++r) {
           if (row0 + r < a.N) {
             float o = v[r];
             if constexpr (EPI == GV_RESIDUAL) o += bf2f(a.res[(int64_t)m * a.ldr + row0 + r]);  // bf16 output + bf16 residual, rounded
@@ -227,7 +228,7 @@ __global__ __launch_bounds__(256, 2) void gemv_kernel(const GemvArgs a) {
       }
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+    for (int r = 0; r < RPW; ++r)
 #pragma unroll
       for (int m = 0; m < MT; ++m) acc[r][m] = 0.f;
   };
@@ -258,21 +259,23 @@ __global__ __launch_bounds__(256, 2) void gemv_kernel(const GemvArgs a) {
   }
 }
 
-template <int MT, int EPI>
+template <int MT, int EPI, int RPW>
 static int launch_gemv_n(const GemvArgs& a, int grid, size_t lds, hipStream_t stream) {
-  if (a.norm_w) hipLaunchKernelGGL((gemv_kernel<MT, EPI, true>), dim3(grid), dim3(256), lds, stream, a);
-  else hipLaunchKernelGGL((gemv_kernel<MT, EPI, false>), dim3(grid), dim3(256), lds, stream, a);
+  if (a.norm_w) hipLaunchKernelGGL((gemv_kernel<MT, EPI, true, RPW>), dim3(grid), dim3(256), lds, stream, a);
+  else hipLaunchKernelGGL((gemv_kernel<MT, EPI, false, RPW>), dim3(grid), dim3(256), lds, stream, a);
   LLX_LAUNCH_CHECK("llx_gemv_bf16");
   return LLX_OK;
 }
 
-template <int MT>
+template <int MT, int RPW>
 static int launch_gemv_m(const GemvArgs& a, int epi, int grid, size_t lds, hipStream_t stream) {
   switch (epi) {
-    case GV_NONE: return launch_gemv_n<MT, GV_NONE>(a, grid, lds, stream);
-    case GV_RESIDUAL: return launch_gemv_n<MT, GV_RESIDUAL>(a, grid, lds, stream);
-    case GV_QKV: return launch_gemv_n<MT, GV_QKV>(a, grid, lds, stream);
-    default: return launch_gemv_n<MT, GV_SWIGLU>(a, grid, lds, stream);
+    case GV_NONE: return launch_gemv_n<MT, GV_NONE, RPW>(a, grid, lds, stream);
+    case GV_RESIDUAL: return launch_gemv_n<MT, GV_RESIDUAL, RPW>(a, grid, lds, stream);
+    case GV_QKV: return launch_gemv_n<MT, GV_QKV, RPW>(a, grid, lds, stream);
+    default:
+      if constexpr (RPW == 4) return launch_gemv_n<MT, GV_SWIGLU, 4>(a, grid, lds, stream);
+      else return LLX_ERR_ARG;
   }
 }
 
@@ -325,11 +328,16 @@ extern "C" int llx_gemv_bf16(const void* w0, int64_t ldw0, int64_t n0, const voi
   a.t_off[0] = 0; a.t_off[1] = (int)rank0; a.t_off[2] = (int)(rank0 + rank1);
   a.t = (const bf16_t*)t; a.ldt = ldt; a.lora_scale = lora_scale;
   if (n1 == 0 && lora) { a.bext[1] = a.bext[2] = a.bext[0]; a.ldb[1] = a.ldb[2] = a.ldb[0]; a.rank[1] = a.rank[2] = a.rank[0]; a.t_off[1] = a.t_off[2] = 0; }
-  const int64_t groups = epilogue == GV_SWIGLU ? (N / 2 + 1) / 2 : (N + 3) / 4;
-  // 2 workgroups of 4 waves per CU; the wave count is trimmed so that every wave gets the same number of row groups where possible
-  const int64_t per_wave = cdiv64(groups, 2048);
+  // rows per wave: 4; 2 where four would leave half of the 2048 wave slots (2 workgroups of 4 waves per CU) empty
+  static const int rpw_knob = [] { const char* e = getenv("LLX_GEMV_RPW"); return e ? atoi(e) : 0; }();
+  const int rpw = epilogue == GV_SWIGLU ? 4 : (rpw_knob == 2 || rpw_knob == 4 ? rpw_knob : ((N + 3) / 4 <= 1024 ? 2 : 4));
+  const int64_t groups = epilogue == GV_SWIGLU ? (N / 2 + 1) / 2 : (N + rpw - 1) / rpw;
+  // the wave count is trimmed so that every wave gets the same number of row groups where possible
+  static const int wave_cap = [] { const char* e = getenv("LLX_GEMV_WAVES"); return e && atoi(e) >= 256 ? atoi(e) : 2048; }();
+  const int64_t per_wave = cdiv64(groups, wave_cap);
   const int grid = (int)cdiv64(cdiv64(groups, per_wave), 4);
-  const int64_t Kp = cdiv64(K, 1024) * 1024;
+  const int64_t kstep = 512 * (8 / rpw);
+  const int64_t Kp = cdiv64(K, kstep) * kstep;
   // the build for m rows stages MT = 1 | 2 | 4 rows of x in LDS; above 64 KiB the rows go in pairs (two passes over the weights)
   auto run = [&](int m0, int mc) -> int {
     GemvArgs b = a;
@@ -342,10 +350,17 @@ extern "C" int llx_gemv_bf16(const void* w0, int64_t ldw0, int64_t n0, const voi
     if (a.t) b.t = a.t + (int64_t)m0 * a.ldt;
     const int MT = mc == 1 ? 1 : (mc == 2 ? 2 : 4);
     const size_t lds = (size_t)MT * Kp * 2 + 64;
+    if (rpw == 2) {
+      switch (MT) {
+        case 1: return launch_gemv_m<1, 2>(b, epilogue, grid, lds, stream);
+        case 2: return launch_gemv_m<2, 2>(b, epilogue, grid, lds, stream);
+        default: return launch_gemv_m<4, 2>(b, epilogue, grid, lds, stream);
+      }
+    }
     switch (MT) {
-      case 1: return launch_gemv_m<1>(b, epilogue, grid, lds, stream);
-      case 2: return launch_gemv_m<2>(b, epilogue, grid, lds, stream);
-      default: return launch_gemv_m<4>(b, epilogue, grid, lds, stream);
+      case 1: return launch_gemv_m<1, 4>(b, epilogue, grid, lds, stream);
+      case 2: return launch_gemv_m<2, 4>(b, epilogue, grid, lds, stream);
+      default: return launch_gemv_m<4, 4>(b, epilogue, grid, lds, stream);
     }
   };
   if (M > 2 && 4 * Kp * 2 + 64 > 64 * 1024) {
