@@ -2,7 +2,8 @@
 //   shape 0: v_mfma_f32_16x16x32_bf16, a 64 x 64 output patch per wave and iteration = 16 instructions (4 A x 4 B fragments, k = 32)
 //   shape 1: v_mfma_f32_32x32x16_bf16, the same patch = 8 instructions (2 A x 2 B fragments x 2 k-steps)
 // Both read 32 operand registers per iteration and hold 64 accumulators; the loop runs long enough (~1 s) for the power cap to act.
-// Operands are random bf16 bit patterns (zeros would understate the power draw).  Prints PFLOP/s per shape and waves per SIMD.
+// Operands are random bf16 bit patterns (zeros would understate the power draw).  Prints PFLOP/s per shape and waves per SIMD, the
+// s_memtime cycles one instruction occupies a SIMD, and the clock those cycles imply.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -13,7 +14,9 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 
 template <int SHAPE>
-__global__ __launch_bounds__(512) void mfma_kernel(const u32x4* src, int iters, float* sink) {
+__global__ __launch_bounds__(512) void mfma_kernel(const u32x4* src, int iters, float* sink, unsigned long long* cyc) {
+  unsigned long long t0, t1;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
   u32x4 fr[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) fr[i] = src[(threadIdx.x + i * 512) & 4095];
@@ -62,21 +65,30 @@ __global__ __launch_bounds__(512) void mfma_kernel(const u32x4* src, int iters, 
         for (int e = 0; e < 16; ++e) s += acc[i][j][e];
     if (s == 1.2345f) sink[0] = s;
   }
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
+  if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
 }
 
 template <int SHAPE>
 static void run(const u32x4* src, float* sink, int wps, int iters) {
+  static unsigned long long* cyc = nullptr;
+  if (!cyc) hipMalloc(&cyc, 256 * 8);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   const int threads = 256 * wps, grid = 256;  // wps waves per SIMD on every CU
   float ms = 0;
   for (int rep = 0; rep < 2; ++rep) {
     hipEventRecord(e0);
-    hipLaunchKernelGGL((mfma_kernel<SHAPE>), dim3(grid), dim3(threads), 0, 0, src, iters, sink);
+    hipLaunchKernelGGL((mfma_kernel<SHAPE>), dim3(grid), dim3(threads), 0, 0, src, iters, sink, cyc);
     hipEventRecord(e1); hipEventSynchronize(e1);
     hipEventElapsedTime(&ms, e0, e1);
   }
   const double flops = 2.0 * 64 * 64 * 32 * (double)iters * (threads / 64) * grid;
-  printf("%s  %d wave(s)/SIMD  %8.1f ms  %6.3f PFLOP/s\n", SHAPE == 0 ? "16x16x32" : "32x32x16", wps, ms, flops / (ms * 1e-3) / 1e15);
+  unsigned long long h[256];
+  hipMemcpy(h, cyc, 256 * 8, hipMemcpyDeviceToHost);
+  double avg = 0; for (int i = 0; i < 256; ++i) avg += (double)h[i]; avg /= 256;
+  const double per_simd = (double)iters * (SHAPE == 0 ? 16 : 8) * wps;  // MFMA instructions per SIMD
+  printf("%s  %d wave(s)/SIMD  %8.1f ms  %6.3f PFLOP/s  %5.2f cycles per instruction and SIMD  clock %.2f GHz\n", SHAPE == 0 ? "16x16x32" : "32x32x16", wps, ms,
+         flops / (ms * 1e-3) / 1e15, avg / per_simd, avg / (ms * 1e-3) / 1e9);
   fflush(stdout);
 }
 
