@@ -673,7 +673,7 @@ __global__ __launch_bounds__(SNT_WAVES * 64) void rmsnorm_skinny_nt_kernel(const
 #pragma unroll
       for (int h = 0; h < 2; ++h) gv[p][h] = *reinterpret_cast<const bf16x8_t*>(grow + p * 64 + 8 * h);
     }
-  constexpr int RSN_PRE = NB == 4 ? 2 : 4;
+  constexpr int RSN_PRE = NB >= 3 ? 2 : 4;
   bf16x8_t bpre[RSN_PRE][2][NB];
 #pragma unroll
   for (int p = 0; p < RSN_PRE; ++p)
@@ -750,7 +750,7 @@ extern "C" int llx_rmsnorm_skinny_nt(const void* x, const void* g, const void* W
   const dim3 grid((unsigned)cdiv64(M, 16)), block(SNT_WAVES * 64);
   const int nb = (int)cdiv64(R, 16);
 #define L(N) hipLaunchKernelGGL((rmsnorm_skinny_nt_kernel<N>), grid, block, 0, stream, (const bf16_t*)x, (const bf16_t*)g, (const bf16_t*)W, ldw, (bf16_t*)y, rstd, (bf16_t*)t, (int)M, (int)D, (int)R, eps)
-  if (nb == 1) L(1); else if (nb == 2) L(2); else L(4);
+  if (nb == 1) L(1); else if (nb == 2) L(2); else if (nb == 3) L(3); else L(4);
 #undef L
   LLX_LAUNCH_CHECK("llx_rmsnorm_skinny_nt");
   return LLX_OK;
