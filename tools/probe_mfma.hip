@@ -1,6 +1,7 @@
 // Microbenchmark: sustained bf16 MFMA rate of the whole chip by instruction shape (gfx950), operands in registers, no memory traffic.
 //   shape 0: v_mfma_f32_16x16x32_bf16, a 64 x 64 output patch per wave and iteration = 16 instructions (4 A x 4 B fragments, k = 32)
 //   shape 1: v_mfma_f32_32x32x16_bf16, the same patch = 8 instructions (2 A x 2 B fragments x 2 k-steps)
+//   shape 2: v_mfma_i32_16x16x64_i8, the patch at k = 64 = 16 instructions (random bytes)
 // Both read 32 operand registers per iteration and hold 64 accumulators; the loop runs long enough (~1 s) for the power cap to act.
 // Operands are random bf16 bit patterns (zeros would understate the power draw).  Prints PFLOP/s per shape and waves per SIMD, the
 // s_memtime cycles one instruction occupies a SIMD, and the clock those cycles imply.
@@ -12,6 +13,7 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(4))) int i32x4;
 
 template <int SHAPE>
 __global__ __launch_bounds__(512) void mfma_kernel(const u32x4* src, int iters, float* sink, unsigned long long* cyc) {
@@ -20,7 +22,26 @@ __global__ __launch_bounds__(512) void mfma_kernel(const u32x4* src, int iters, 
   u32x4 fr[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) fr[i] = src[(threadIdx.x + i * 512) & 4095];
-  if constexpr (SHAPE == 0) {
+  if constexpr (SHAPE == 2) {
+    i32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = i32x4{0, 0, 0, 0};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, fr[i]), __builtin_bit_cast(i32x4, fr[4 + j]), acc[i][j], 0, 0, 0);
+    }
+    int s = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) s += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    if (s == 12345) sink[0] = (float)s;
+  } else if constexpr (SHAPE == 0) {
     f32x4 acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -82,13 +103,16 @@ static void run(const u32x4* src, float* sink, int wps, int iters) {
     hipEventRecord(e1); hipEventSynchronize(e1);
     hipEventElapsedTime(&ms, e0, e1);
   }
-  const double flops = 2.0 * 64 * 64 * 32 * (double)iters * (threads / 64) * grid;
+  const double flops = 2.0 * 64 * 64 * (SHAPE == 2 ? 64 : 32) * (double)iters * (threads / 64) * grid;
   unsigned long long h[256];
   hipMemcpy(h, cyc, 256 * 8, hipMemcpyDeviceToHost);
   double avg = 0; for (int i = 0; i < 256; ++i) avg += (double)h[i]; avg /= 256;
-  const double per_simd = (double)iters * (SHAPE == 0 ? 16 : 8) * wps;  // MFMA instructions per SIMD
-  printf("%s  %d wave(s)/SIMD  %8.1f ms  %6.3f PFLOP/s  %5.2f cycles per instruction and SIMD  clock %.2f GHz\n", SHAPE == 0 ? "16x16x32" : "32x32x16", wps, ms,
-         flops / (ms * 1e-3) / 1e15, avg / per_simd, avg / (ms * 1e-3) / 1e9);
+  const double per_wave = (double)iters * (SHAPE == 1 ? 8 : 16);  // MFMA instructions per wave
+  if (wps == 1)
+    printf("%s  1 wave/SIMD   %8.1f ms  %6.3f P(FL)OP/s  %5.2f cycles per instruction  clock %.2f GHz\n", SHAPE == 0 ? "bf16 16x16x32" : (SHAPE == 1 ? "bf16 32x32x16" : "i8   16x16x64"),
+           ms, flops / (ms * 1e-3) / 1e15, avg / per_wave, avg / (ms * 1e-3) / 1e9);
+  else  // (the s_memtime count of a wave that shares its SIMD is not comparable: only the rate is printed)
+    printf("%s  %d waves/SIMD  %8.1f ms  %6.3f P(FL)OP/s\n", SHAPE == 0 ? "bf16 16x16x32" : (SHAPE == 1 ? "bf16 32x32x16" : "i8   16x16x64"), wps, ms, flops / (ms * 1e-3) / 1e15);
   fflush(stdout);
 }
 
@@ -102,12 +126,14 @@ int main() {
     h[i] = (hi << 16) | lo;
   }
   hipMemcpy(src, h, 4096 * 16, hipMemcpyHostToDevice);
-  const int iters = 6000000;  // ~0.8 s at 2 PF/s and one wave per SIMD
+  const int iters = 3000000;  // ~0.4 s at 2 PF/s and one wave per SIMD
   for (int rep = 0; rep < 2; ++rep) {
     run<0>(src, sink, 1, iters);
     run<1>(src, sink, 1, iters);
-    run<0>(src, sink, 2, iters / 2);
-    run<1>(src, sink, 2, iters / 2);
+    run<2>(src, sink, 1, iters);
+    run<0>(src, sink, 2, iters);
+    run<1>(src, sink, 2, iters);
+    run<2>(src, sink, 2, iters);
   }
   return 0;
 }
