@@ -48,6 +48,24 @@ __device__ __forceinline__ float dot8(const u32x4_t& w, const float (&xf)[8]) {
   return s;
 }
 
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+// Sum over the 64 lanes, every lane gets it, all in the vector pipe: DPP inside the rows of 16 (quad swaps, half mirror, mirror), then
+// v_permlane16_swap / v_permlane32_swap pair the rows (common.h's wave_sum takes six trips through the LDS crossbar; other sum order).
+__device__ __forceinline__ float wave_sum_valu(float v) {
+  v += dpp_f32<0xB1>(v);
+  v += dpp_f32<0x4E>(v);
+  v += dpp_f32<0x141>(v);
+  v += dpp_f32<0x140>(v);
+  // (__uint_as_float on the elements, not __builtin_bit_cast: hipcc 7.2 reads element 0 for BOTH halves of the pair through bit_cast)
+  const auto s16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(s16[0]) + __uint_as_float(s16[1]);
+  const auto s32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(s32[0]) + __uint_as_float(s32[1]);
+}
+
 // RPW output rows per wave at a time (4, or 2 for the narrow projections: twice the waves, each with the same 8 loads in flight, so
 // that 4096 output rows still put 2 workgroups on every CU); a step is 8 / RPW pieces of 512 elements (64 lanes x 8) of those rows.
 template <int MT, int EPI, bool NORM, int RPW = 4>
@@ -177,7 +195,7 @@ __global__ __launch_bounds__(256, 2) void gemv_kernel(const GemvArgs a) {
 #pragma unroll
     for (int r = 0; r < RPW; ++r)
 #pragma unroll
-      for (int m = 0; m < MT; ++m) acc[r][m] = wave_sum(acc[r][m]);
+      for (int m = 0; m < MT; ++m) acc[r][m] = wave_sum_valu(acc[r][m]);
     // ---- epilogue: lane m writes token m (every lane holds every sum)
     if (lane < MT && lane < a.M) {
       float v[4] = {0.f, 0.f, 0.f, 0.f};
@@ -442,8 +460,11 @@ struct DecodeArgs {
 // DEC_KPG = keys per lane group and step: 4 for up to 4 query rows (the batch-1 decode step), fewer for more rows (register budget)
 template <int ROWS, int DEC_KPG>
 __global__ __launch_bounds__(256) void attn_decode_kernel(const DecodeArgs a) {
-  __shared__ float sm_o[4][ROWS][HD];
-  __shared__ float sm_ml[4][ROWS][2];
+  // partials that meet in LDS: one per wave after a shuffle merge of its four lane groups, or - for up to 4 rows, where 16 partials fit
+  // in 32 KB - one per lane group straight from the registers (the 80 dependent shuffles of the merge cost 1.6 us of a 7.5 us block)
+  constexpr int NPART = ROWS <= 4 ? 16 : 4;
+  __shared__ float sm_o[NPART][ROWS][HD];
+  __shared__ float sm_ml[NPART][ROWS][2];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int split = blockIdx.x, kvh = blockIdx.y, b = blockIdx.z;
@@ -453,15 +474,16 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const DecodeArgs a) {
   const int span = ((ext + a.nsplit - 1) / a.nsplit + 15) & ~15;  // keys per workgroup, multiple of 16
   const int k_lo = split * span, k_hi = min(ext, k_lo + span);
 
-  float qf[ROWS][8];
+  // (the query rows are only REQUESTED here: they are unpacked after the first K / V loads have been issued - unpacking them first
+  // put a full memory round trip, 1.2 us, in front of those loads)
+  u32x4_t qraw[ROWS];
 #pragma unroll
   for (int r = 0; r < ROWS; ++r) {
     const int g = r / a.M, m = r % a.M;  // row r = (head g of the group, token m)
     const int h = kvh * G + min(g, G - 1);
-    const u32x4_t qv = *reinterpret_cast<const u32x4_t*>(a.q + b * a.q_sb + h * a.q_sh + (int64_t)m * a.q_ss + c * 8);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { qf[r][2 * e] = bflo(qv[e]) * a.scale_log2; qf[r][2 * e + 1] = bfhi(qv[e]) * a.scale_log2; }
+    qraw[r] = *reinterpret_cast<const u32x4_t*>(a.q + b * a.q_sb + h * a.q_sh + (int64_t)m * a.q_ss + c * 8);
   }
+  float qf[ROWS][8];
   float mx[ROWS], ls[ROWS], o[ROWS][8];
 #pragma unroll
   for (int r = 0; r < ROWS; ++r) {
@@ -515,10 +537,12 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const DecodeArgs a) {
         float d = 0.f;
 #pragma unroll
         for (int e = 0; e < 8; ++e) d = __builtin_fmaf(qf[r][e], kf[e], d);
-        d += __shfl_xor(d, 1, 64);
-        d += __shfl_xor(d, 2, 64);
-        d += __shfl_xor(d, 4, 64);
-        d += __shfl_xor(d, 8, 64);
+        // sum over the 16 lanes of the key's group in the vector pipe (DPP: quad swaps, then the mirrors pair quads and halves - the same
+        // additions as an xor butterfly, without four trips through the LDS crossbar)
+        d += dpp_f32<0xB1>(d);   // quad_perm [1,0,3,2]
+        d += dpp_f32<0x4E>(d);   // quad_perm [2,3,0,1]
+        d += dpp_f32<0x141>(d);  // row_half_mirror
+        d += dpp_f32<0x140>(d);  // row_mirror
         const bool ok = shared_mask ? ((allow[j] >> (r % a.M)) & 1u) != 0 : ((allow[j] >> r) & 1u) != 0;
         s[j][r] = ok ? d : -INFINITY;
       }
@@ -550,6 +574,11 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const DecodeArgs a) {
     uint8_t mbA[DEC_KPG][ROWS], mbB[DEC_KPG][ROWS];
     int k0 = k_lo + wave * (4 * DEC_KPG);
     if (k0 < k_hi) load_step(k0, kvA, vvA, mbA);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { qf[r][2 * e] = bflo(qraw[r][e]) * a.scale_log2; qf[r][2 * e + 1] = bfhi(qraw[r][e]) * a.scale_log2; }
     while (k0 < k_hi) {
       if (k0 + kstep < k_hi) load_step(k0 + kstep, kvB, vvB, mbB);
       compute_step(k0, kvA, vvA, mbA);
@@ -564,20 +593,23 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const DecodeArgs a) {
   // through LDS: ONE partial (m, l, o) per workgroup and query row
 #pragma unroll
   for (int r = 0; r < ROWS; ++r) {
+    if constexpr (NPART == 4) {
 #pragma unroll
-    for (int off = 16; off <= 32; off <<= 1) {
-      const float m2 = __shfl_xor(mx[r], off, 64), l2 = __shfl_xor(ls[r], off, 64);
-      const float mn = fmaxf(mx[r], m2);
-      const float fa = mn == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(mx[r] - mn), fb = mn == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(m2 - mn);
-      ls[r] = ls[r] * fa + l2 * fb;
+      for (int off = 16; off <= 32; off <<= 1) {
+        const float m2 = __shfl_xor(mx[r], off, 64), l2 = __shfl_xor(ls[r], off, 64);
+        const float mn = fmaxf(mx[r], m2);
+        const float fa = mn == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(mx[r] - mn), fb = mn == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(m2 - mn);
+        ls[r] = ls[r] * fa + l2 * fb;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) o[r][e] = o[r][e] * fa + __shfl_xor(o[r][e], off, 64) * fb;
-      mx[r] = mn;
+        for (int e = 0; e < 8; ++e) o[r][e] = o[r][e] * fa + __shfl_xor(o[r][e], off, 64) * fb;
+        mx[r] = mn;
+      }
     }
-    if (grp == 0) {
-      *reinterpret_cast<f32x4_t*>(&sm_o[wave][r][c * 8]) = f32x4_t{o[r][0], o[r][1], o[r][2], o[r][3]};
-      *reinterpret_cast<f32x4_t*>(&sm_o[wave][r][c * 8 + 4]) = f32x4_t{o[r][4], o[r][5], o[r][6], o[r][7]};
-      if (c == 0) { sm_ml[wave][r][0] = mx[r]; sm_ml[wave][r][1] = ls[r]; }
+    const int slot = NPART == 4 ? wave : wave * 4 + grp;
+    if (NPART == 16 || grp == 0) {
+      *reinterpret_cast<f32x4_t*>(&sm_o[slot][r][c * 8]) = f32x4_t{o[r][0], o[r][1], o[r][2], o[r][3]};
+      *reinterpret_cast<f32x4_t*>(&sm_o[slot][r][c * 8 + 4]) = f32x4_t{o[r][4], o[r][5], o[r][6], o[r][7]};
+      if (c == 0) { sm_ml[slot][r][0] = mx[r]; sm_ml[slot][r][1] = ls[r]; }
     }
   }
   __syncthreads();
@@ -585,10 +617,12 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const DecodeArgs a) {
     const int r = idx >> 7, d = idx & (HD - 1);
     const int g = r / a.M, m = r % a.M;
     if (g >= G) continue;
-    float mm = fmaxf(fmaxf(sm_ml[0][r][0], sm_ml[1][r][0]), fmaxf(sm_ml[2][r][0], sm_ml[3][r][0]));
+    float mm = -INFINITY;
+#pragma unroll
+    for (int w = 0; w < NPART; ++w) mm = fmaxf(mm, sm_ml[w][r][0]);
     float num = 0.f, den = 0.f;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
+    for (int w = 0; w < NPART; ++w) {
       const float f = sm_ml[w][r][0] == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(sm_ml[w][r][0] - mm);
       num += sm_o[w][r][d] * f;
       den += sm_ml[w][r][1] * f;
