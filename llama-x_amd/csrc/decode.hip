@@ -74,22 +74,23 @@ __global__ __launch_bounds__(256, 2) void gemv_kernel(const GemvArgs a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int K = a.K;
-  static_assert(RPW == 4 || (RPW == 2 && EPI != GV_SWIGLU), "rows per wave");
+  static_assert(RPW == 4 || RPW == 2, "rows per wave");
   constexpr int PIECES = 8 / RPW, STEP = 512 * PIECES;
   const int nsteps = (K + STEP - 1) / STEP;  // a step = PIECES 512-element pieces of RPW weight rows: 8 x 16-byte loads per lane
   const int Kp = nsteps * STEP;              // the LDS copy of x is zero-padded to whole steps: weight lanes past K multiply zeros
   bf16_t* xs = reinterpret_cast<bf16_t*>(smem);  // [MT][Kp]
   float* red = reinterpret_cast<float*>(smem + (size_t)MT * Kp * 2);
 
-  // ---- row groups: 4 output rows per wave at a time.  SWIGLU: the gate and up rows of two hidden units (W[0] rows 2g, 2g+1 and
-  // W[1] rows 2g, 2g+1), so that the epilogue has g and u of one unit side by side.
+  // ---- row groups: RPW output rows per wave at a time.  SWIGLU: the gate and up rows of RPW / 2 hidden units (W[0] rows UPG g .. and
+  // W[1] rows UPG g ..; r = matrix * UPG + unit), so that the epilogue has g and u of one unit side by side.
+  constexpr int UPG = RPW / 2;  // hidden units per SwiGLU group
   struct Grp { const bf16_t* wr[RPW]; int row0, seg; };
   auto setup = [&](int g, Grp& G) {
     if constexpr (EPI == GV_SWIGLU) {
       const int half = a.N / 2;
-      G.row0 = 2 * g; G.seg = 0;
+      G.row0 = UPG * g; G.seg = 0;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) G.wr[r] = a.W[r >> 1] + (int64_t)min(G.row0 + (r & 1), half - 1) * a.ldw[r >> 1];
+      for (int r = 0; r < RPW; ++r) G.wr[r] = a.W[r / UPG] + (int64_t)min(G.row0 + (r % UPG), half - 1) * a.ldw[r / UPG];
     } else {
       G.row0 = RPW * g;
       G.seg = G.row0 >= a.seg_end[0] ? (G.row0 >= a.seg_end[1] ? 2 : 1) : 0;  // wave-uniform (segment boundaries are multiples of 4)
@@ -109,7 +110,7 @@ __global__ __launch_bounds__(256, 2) void gemv_kernel(const GemvArgs a) {
     }
   };
   const int nwaves = gridDim.x * 4;
-  const int ngroups = EPI == GV_SWIGLU ? (a.N / 2 + 1) / 2 : (a.N + RPW - 1) / RPW;
+  const int ngroups = EPI == GV_SWIGLU ? (a.N / 2 + UPG - 1) / UPG : (a.N + RPW - 1) / RPW;
   int g = blockIdx.x * 4 + wave, s = 0;
   Grp cur, nxt;
   u32x4_t WA[8], WB[8];
@@ -171,12 +172,12 @@ __global__ __launch_bounds__(256, 2) void gemv_kernel(const GemvArgs a) {
     // LoRA extension: lanes 0 .. rank/8-1 hold 8 elements of the row's B factor each
 #pragma unroll
     for (int r = 0; r < RPW; ++r) {
-      const int s2 = EPI == GV_SWIGLU ? (r >> 1) : seg;
+      const int s2 = EPI == GV_SWIGLU ? (r / UPG) : seg;
       const bf16_t* bp = a.bext[s2];
       if (bp != nullptr && lane * 8 < a.rank[s2]) {
         int lrow;
         if constexpr (EPI == GV_SWIGLU) {
-          lrow = min(row0 + (r & 1), a.N / 2 - 1);
+          lrow = min(row0 + (r % UPG), a.N / 2 - 1);
         } else {
           const int base = seg == 0 ? 0 : a.seg_end[seg - 1];
           lrow = min(row0 - base + r, a.seg_end[seg] - 1 - base);
@@ -211,8 +212,8 @@ __global__ __launch_bounds__(256, 2) void gemv_kernel(const GemvArgs a) {
         // h = silu(g) * u with the roundings of the bf16 eager graph (modelling/llama.py:150-152), as swiglu_fwd8
         const int half = a.N / 2;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const float gg = v[j], uu = v[2 + j];
+        for (int j = 0; j < UPG; ++j) {
+          const float gg = v[j], uu = v[UPG + j];
           const float sg = bf2f(f2bf(gg * sigmoidf_(gg)));
           if (row0 + j < half) a.out[(int64_t)m * a.ldo + row0 + j] = f2bf(sg * uu);
         }
@@ -291,9 +292,7 @@ static int launch_gemv_m(const GemvArgs& a, int epi, int grid, size_t lds, hipSt
     case GV_NONE: return launch_gemv_n<MT, GV_NONE, RPW>(a, grid, lds, stream);
     case GV_RESIDUAL: return launch_gemv_n<MT, GV_RESIDUAL, RPW>(a, grid, lds, stream);
     case GV_QKV: return launch_gemv_n<MT, GV_QKV, RPW>(a, grid, lds, stream);
-    default:
-      if constexpr (RPW == 4) return launch_gemv_n<MT, GV_SWIGLU, 4>(a, grid, lds, stream);
-      else return LLX_ERR_ARG;
+    default: return launch_gemv_n<MT, GV_SWIGLU, RPW>(a, grid, lds, stream);
   }
 }
 
@@ -346,10 +345,12 @@ extern "C" int llx_gemv_bf16(const void* w0, int64_t ldw0, int64_t n0, const voi
   a.t_off[0] = 0; a.t_off[1] = (int)rank0; a.t_off[2] = (int)(rank0 + rank1);
   a.t = (const bf16_t*)t; a.ldt = ldt; a.lora_scale = lora_scale;
   if (n1 == 0 && lora) { a.bext[1] = a.bext[2] = a.bext[0]; a.ldb[1] = a.ldb[2] = a.ldb[0]; a.rank[1] = a.rank[2] = a.rank[0]; a.t_off[1] = a.t_off[2] = 0; }
-  // rows per wave: 4; 2 where four would leave half of the 2048 wave slots (2 workgroups of 4 waves per CU) empty
+  // rows per wave: 2 (steps of 2048 elements per row: half the dependent steps of the 4-row form on every product of the decode step and
+  // twice the waves where N <= 4096 would fill only half of the 2048 slots: 3.51 -> 3.39 ms per token; one row per wave: 3.43);
+  // LLX_GEMV_RPW=4: the 4-row form
   static const int rpw_knob = [] { const char* e = getenv("LLX_GEMV_RPW"); return e ? atoi(e) : 0; }();
-  const int rpw = epilogue == GV_SWIGLU ? 4 : (rpw_knob == 2 || rpw_knob == 4 ? rpw_knob : ((N + 3) / 4 <= 1024 ? 2 : 4));
-  const int64_t groups = epilogue == GV_SWIGLU ? (N / 2 + 1) / 2 : (N + rpw - 1) / rpw;
+  const int rpw = rpw_knob == 4 ? 4 : 2;
+  const int64_t groups = epilogue == GV_SWIGLU ? (N / 2 + rpw / 2 - 1) / (rpw / 2) : (N + rpw - 1) / rpw;
   // the wave count is trimmed so that every wave gets the same number of row groups where possible
   static const int wave_cap = [] { const char* e = getenv("LLX_GEMV_WAVES"); return e && atoi(e) >= 256 ? atoi(e) : 2048; }();
   const int64_t per_wave = cdiv64(groups, wave_cap);

@@ -50,6 +50,41 @@ def test_gemv_plain_and_residual(K, cuda, M, K_, ns, norm):
     assert torch.equal(got, K.gemv([w.to(cuda) for w in ws], x.to(cuda), norm=(nw.to(cuda), 1e-5) if norm else None))
 
 
+def test_gemv_four_row_build_is_bit_identical(K, cuda, tmp_path):
+    """LLX_GEMV_RPW=4 (four output rows per wave, steps of 1024 elements - the knob is read once per process, hence the child process):
+    every lane adds the same products in the same order as in the default two-row build, so the outputs agree bit for bit - plain,
+    q|k|v (RoPE + cache write) and SwiGLU epilogues."""
+    import os, subprocess, sys
+
+    script = r"""
+import sys, torch
+sys.path[:0] = [sys.argv[2] + "/llama-x_amd", sys.argv[2]]
+from llx import kernels as K
+torch.manual_seed(5)
+dev = "cuda"
+x = torch.randn(1, 1024, device=dev).bfloat16(); nw = (1 + 0.1 * torch.randn(1024, device=dev)).bfloat16()
+w = [(0.05 * torch.randn(n, 1024, device=dev)).bfloat16() for n in (512, 128, 128)]
+out = {"plain": K.gemv(w, x, norm=(nw, 1e-5))}
+rope = torch.randn(1, 64, 2, device=dev)
+kc = torch.zeros(1, 1, 16, 128, device=dev, dtype=torch.bfloat16); vc = torch.zeros_like(kc)
+pos = torch.tensor([3], device=dev)
+out["q"] = K.gemv(w, x, norm=(nw, 1e-5), epilogue=K.GV_QKV, qkv=(rope, 512, 128, kc, vc, pos)); out["kc"] = kc; out["vc"] = vc
+g = [(0.05 * torch.randn(768, 1024, device=dev)).bfloat16() for _ in range(2)]
+out["h"] = K.gemv(g, x, norm=(nw, 1e-5), epilogue=K.GV_SWIGLU)
+torch.save({k: v.cpu() for k, v in out.items()}, sys.argv[1])
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for rpw in ("2", "4"):
+        path = str(tmp_path / f"gemv_rpw{rpw}.pt")
+        env = dict(os.environ, LLX_GEMV_RPW=rpw)
+        subprocess.run([sys.executable, "-c", script, path, root], check=True, env=env, timeout=300)
+        res[rpw] = torch.load(path, weights_only=True)
+    for k in res["2"]:
+        assert torch.equal(res["2"][k], res["4"][k]), k
+    assert float(res["2"]["h"].abs().max()) > 0 and float(res["2"]["kc"].abs().max()) > 0
+
+
 def test_gemv_ragged_rows_and_rejects(K, cuda):
     from llx._lib import LlxError
 
