@@ -54,3 +54,7 @@ x = rn(M, 4096); w = (1 + 0.1 * torch.randn(4096, device=dev, generator=g)).bflo
 for R in (48, 32):
     a = rn(R, 4096)
     bench(f"rmsnorm_skinny_nt x[{M},4096], R={R}", lambda: K.rmsnorm_skinny_nt(x, w, 1e-5, a))
+# weight-gradient side: out[R, N] = scale * u^T . y (first stage: split partials; second stage: the reduce over the splits)
+for N, R in ((4096, 16), (4096, 48), (14336, 16), (6144, 48), (28672, 32)):
+    u = rn(M, 64); y = rn(M, N); out = torch.empty(R, N, device=dev, dtype=torch.bfloat16)
+    bench(f"skinny_tn u[{M},64]^T . y[{M},{N}] (R={R}, both stages)", lambda: K.skinny_tn(u, y, R, 1.0, out, False))
